@@ -1,0 +1,100 @@
+"""ctypes binding of ``csrc/libbdvcil_hip.so`` (C ABI declared in ``include/bdvcil_hip.h``).
+
+The library is loaded lazily and per process (a ctypes handle cannot be pickled; modules that are
+shipped to ``ddp_spawn`` workers re-open it on first use -- SURVEY.md section 8(b) "Threading").
+There is NO fallback: if the shared object is missing or a call fails, a ``RuntimeError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
+ABI_VERSION = 1
+
+_lib = None
+
+
+class ConvGeom(Structure):
+    """Mirror of ``bdv_conv_geom``."""
+    _fields_ = [(n, c_int32) for n in
+                ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'R', 'S', 'stride', 'pad', 'T', 'fold')]
+
+    def key(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+P = c_void_p
+_F3 = c_float * 3
+
+# name -> (restype, argtypes)
+SIGNATURES = {
+    'bdv_last_error': (c_char_p, []),
+    'bdv_abi_version': (c_int, []),
+    'bdv_conv_fprop': (c_int, [P, P, P, POINTER(ConvGeom), P]),
+    'bdv_conv_dgrad': (c_int, [P, P, P, P, P, POINTER(ConvGeom), P]),
+    'bdv_conv_wgrad_workspace_bytes': (c_size_t, [POINTER(ConvGeom)]),
+    'bdv_conv_wgrad': (c_int, [P, P, P, c_float, POINTER(ConvGeom), P, c_size_t, P]),
+    'bdv_bn_workspace_bytes': (c_size_t, [c_int64, c_int]),
+    'bdv_bn_train_stats': (c_int, [P, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_size_t, P]),
+    'bdv_bn_eval_params': (c_int, [c_int, P, P, P, P, c_float, P, P, P]),
+    'bdv_bn_apply': (c_int, [P, P, P, P, P, c_int64, c_int, c_int, P]),
+    'bdv_bn_backward': (c_int, [P, P, P, P, P, P, P, P, P, c_float, c_int64, c_int, c_int, P, c_size_t, P]),
+    'bdv_relu_bwd': (c_int, [P, P, P, P, c_int64, P]),
+    'bdv_add': (c_int, [P, P, P, c_int64, P]),
+    'bdv_nchw3_to_nhwc4': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'bdv_maxpool_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_maxpool_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_avgpool_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'bdv_avgpool_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'bdv_bgmix_normalize_u8': (c_int, [P, P, P, c_float, _F3, _F3, _F3, P, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_lsc_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_lsc_bwd': (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_linear_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    'bdv_linear_bwd': (c_int, [P, P, P, P, P, P, c_float, c_int, c_int, c_int, P]),
+    'bdv_consensus_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'bdv_consensus_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'bdv_dropout': (c_int, [P, P, c_int64, c_float, c_uint64, P]),
+    'bdv_lsc_loss': (c_int, [P, P, P, c_float, c_int, P, P, P, c_int, c_int, P]),
+    'bdv_softce_loss': (c_int, [P, P, P, P, P, c_int, c_int, P]),
+    'bdv_icarl_targets': (c_int, [P, P, c_int, P, c_int, c_int, P]),
+    'bdv_softmax_mean': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_topk_acc': (c_int, [P, P, P, c_int, c_int, P]),
+    'bdv_reduce_workspace_bytes': (c_size_t, []),
+    'bdv_kd_mse_fwd': (c_int, [P, P, P, c_int64, P, c_size_t, P]),
+    'bdv_kd_mse_bwd': (c_int, [P, P, P, c_float, P, c_int64, P]),
+    'bdv_multi_sqnorm': (c_int, [P, P, c_int, P, P, c_size_t, P]),
+    'bdv_clip_coef': (c_int, [P, c_float, c_float, P, P]),
+    'bdv_multi_sgd': (c_int, [P, P, P, P, P, P, c_int, c_float, c_float, P, P]),
+}
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def lib():
+    """Return the loaded library, loading it on first use.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionError(
+                f'HIP extension not built: {LIB_PATH} is missing. Run `python -c "import __graft_entry__ as g; '
+                f'g.build()"` (or `make -C {os.path.dirname(LIB_PATH)}`). There is no CPU fallback.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.bdv_abi_version() != ABI_VERSION:
+            raise HipExtensionError(f'ABI mismatch: library {handle.bdv_abi_version()} != binding {ABI_VERSION}')
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str = ''):
+    if code != 0:
+        msg = lib().bdv_last_error()
+        raise HipExtensionError(f'{what or "bdvcil_hip"} failed with code {code}: {msg.decode() if msg else ""}')

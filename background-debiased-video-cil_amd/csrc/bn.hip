@@ -1,0 +1,385 @@
+// BatchNorm2d (train / eval) on NHWC [M][C] fp32, fused with ReLU and the residual add, plus the
+// backward.  HBM-bound column reductions: partial sums per row-block (fp32), fixed-order final
+// reduction in fp64 (deterministic, no atomics).
+//
+// Replaces UPSTREAM mmaction ConvModule.bn / .activate and the Bottleneck/BasicBlock
+// `out + identity -> relu`.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_RB_TIMES_C = 524288;  // partial-slab capacity in floats per quantity
+
+struct BnGrid {
+  int CVB;  // float4 column vectors per block
+  int RL;   // row lanes per block (CVB * RL == 256)
+  int CC;   // column chunks
+  int RB;   // row blocks
+  int rows_per_block;
+};
+
+BnGrid bn_grid(int64_t M, int C) {
+  BnGrid b;
+  const int cv = C / 4;
+  b.CVB = cv < 64 ? cv : 64;
+  b.RL = 256 / b.CVB;
+  b.CC = (cv + b.CVB - 1) / b.CVB;
+  int64_t rb = (M + 127) / 128;
+  const int64_t cap = 2048 / b.CC > 0 ? 2048 / b.CC : 1;
+  if (rb > cap) rb = cap;
+  if (rb < 1) rb = 1;
+  while (rb * C > MAX_RB_TIMES_C) --rb;
+  b.RB = (int)rb;
+  b.rows_per_block = (int)((M + rb - 1) / rb);
+  return b;
+}
+
+bool bn_c_ok(int C) { return C >= 64 && (C % 256 == 0 || C == 64 || C == 128); }
+
+// ---- forward statistics ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ y, float* __restrict__ psum,
+                                                          float* __restrict__ psq, int64_t M, int C, int CVB, int RL,
+                                                          int rows_per_block) {
+  __shared__ float4 sh[2][256];
+  const int tid = threadIdx.x;
+  const int cv = tid % CVB, rl = tid / CVB;
+  const int c4 = blockIdx.y * CVB + cv;  // float4 column index
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  const int CV = C / 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+  const float4* yp = reinterpret_cast<const float4*>(y);
+  for (int64_t r = r0 + rl; r < r1; r += RL) {
+    const float4 v = yp[r * CV + c4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+  }
+  sh[0][tid] = s;
+  sh[1][tid] = q;
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < RL; ++k) {
+      const float4 a = sh[0][k * CVB + cv], b = sh[1][k * CVB + cv];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+    }
+    reinterpret_cast<float4*>(psum)[(int64_t)blockIdx.x * CV + c4] = s;
+    reinterpret_cast<float4*>(psq)[(int64_t)blockIdx.x * CV + c4] = q;
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int RB, int64_t M, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int r = 0; r < RB; ++r) {
+    s += (double)psum[(int64_t)r * C + c];
+    q += (double)psq[(int64_t)r * C + c];
+  }
+  const double mean = s / (double)M;
+  double var = q / (double)M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  save_mean[c] = meanf;
+  save_invstd[c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - meanf * sc;
+  if (running_mean != nullptr) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_params_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ---- apply -------------------------------------------------------------------------------
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
+                                                        const float4* __restrict__ shift, const float4* __restrict__ res,
+                                                        float4* __restrict__ out, int64_t n4, int CV) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int c4 = (int)(i % CV);
+    const float4 v = y[i], sc = scale[c4], sh = shift[c4];
+    float4 o;
+    o.x = v.x * sc.x + sh.x;
+    o.y = v.y * sc.y + sh.y;
+    o.z = v.z * sc.z + sh.z;
+    o.w = v.w * sc.w + sh.w;
+    if (RES) {
+      const float4 r = res[i];
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    if (RELU) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    out[i] = o;
+  }
+}
+
+// ---- backward ----------------------------------------------------------------------------
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                              const float* __restrict__ y, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* __restrict__ p1,
+                                                              float* __restrict__ p2, int64_t M, int C, int CVB, int RL,
+                                                              int rows_per_block) {
+  __shared__ float4 sh[2][256];
+  const int tid = threadIdx.x;
+  const int cv = tid % CVB, rl = tid / CVB;
+  const int c4 = blockIdx.y * CVB + cv;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  const int CV = C / 4;
+  const float4 mu = reinterpret_cast<const float4*>(mean)[c4];
+  const float4 is = reinterpret_cast<const float4*>(invstd)[c4];
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (int64_t r = r0 + rl; r < r1; r += RL) {
+    const int64_t i = r * CV + c4;
+    float4 g = reinterpret_cast<const float4*>(dout)[i];
+    if (RELU) {
+      const float4 o = reinterpret_cast<const float4*>(out)[i];
+      g.x = o.x > 0.f ? g.x : 0.f;
+      g.y = o.y > 0.f ? g.y : 0.f;
+      g.z = o.z > 0.f ? g.z : 0.f;
+      g.w = o.w > 0.f ? g.w : 0.f;
+    }
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+    s2.x += g.x * ((v.x - mu.x) * is.x);
+    s2.y += g.y * ((v.y - mu.y) * is.y);
+    s2.z += g.z * ((v.z - mu.z) * is.z);
+    s2.w += g.w * ((v.w - mu.w) * is.w);
+  }
+  sh[0][tid] = s1;
+  sh[1][tid] = s2;
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < RL; ++k) {
+      const float4 a = sh[0][k * CVB + cv], b = sh[1][k * CVB + cv];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+    }
+    reinterpret_cast<float4*>(p1)[(int64_t)blockIdx.x * CV + c4] = s1;
+    reinterpret_cast<float4*>(p2)[(int64_t)blockIdx.x * CV + c4] = s2;
+  }
+}
+
+// coef[0][c] = gamma*invstd, coef[1][c] = sum(g)/M, coef[2][c] = sum(g*xhat)/M
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int RB, int64_t M, int C,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float beta_acc,
+                                       float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < RB; ++r) {
+    s1 += (double)p1[(int64_t)r * C + c];
+    s2 += (double)p2[(int64_t)r * C + c];
+  }
+  if (dgamma != nullptr) dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)s2;
+  if (dbeta != nullptr) dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)s1;
+  coef[c] = gamma[c] * invstd[c];
+  coef[C + c] = (float)(s1 / (double)M);
+  coef[2 * C + c] = (float)(s2 / (double)M);
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restrict__ dout, const float4* __restrict__ out,
+                                                            const float4* __restrict__ y, const float4* __restrict__ mean,
+                                                            const float4* __restrict__ invstd, const float4* __restrict__ coef,
+                                                            float4* __restrict__ dy, int64_t n4, int CV) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int c4 = (int)(i % CV);
+    float4 g = dout[i];
+    if (RELU) {
+      const float4 o = out[i];
+      g.x = o.x > 0.f ? g.x : 0.f;
+      g.y = o.y > 0.f ? g.y : 0.f;
+      g.z = o.z > 0.f ? g.z : 0.f;
+      g.w = o.w > 0.f ? g.w : 0.f;
+    }
+    const float4 v = y[i], mu = mean[c4], is = invstd[c4];
+    const float4 a = coef[c4], b = coef[CV + c4], c = coef[2 * CV + c4];
+    float4 d;
+    d.x = a.x * (g.x - b.x - ((v.x - mu.x) * is.x) * c.x);
+    d.y = a.y * (g.y - b.y - ((v.y - mu.y) * is.y) * c.y);
+    d.z = a.z * (g.z - b.z - ((v.z - mu.z) * is.z) * c.z);
+    d.w = a.w * (g.w - b.w - ((v.w - mu.w) * is.w) * c.w);
+    dy[i] = d;
+  }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float4* __restrict__ dout, const float4* __restrict__ out,
+                                                        const float4* __restrict__ add, float4* __restrict__ g, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 d = dout[i];
+    const float4 o = out[i];
+    d.x = o.x > 0.f ? d.x : 0.f;
+    d.y = o.y > 0.f ? d.y : 0.f;
+    d.z = o.z > 0.f ? d.z : 0.f;
+    d.w = o.w > 0.f ? d.w : 0.f;
+    if (add != nullptr) {
+      const float4 a = add[i];
+      d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+    }
+    g[i] = d;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                   float4* __restrict__ out, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 x = a[i], y = b[i];
+    out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+
+int ew_grid(int64_t n4) {
+  int64_t b = (n4 + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" size_t bdv_bn_workspace_bytes(int64_t M, int C) {
+  (void)M;
+  // two partial slabs (<= MAX_RB_TIMES_C floats each) + 3*C coefficients
+  return (size_t)(2 * MAX_RB_TIMES_C + 3 * (size_t)(C > 0 ? C : 0)) * sizeof(float);
+}
+
+extern "C" int bdv_bn_train_stats(const float* y, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                                  float momentum, float* running_mean, float* running_var, float* save_mean,
+                                  float* save_invstd, float* scale, float* shift, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  BDV_REQUIRE(y && gamma && beta && save_mean && save_invstd && scale && shift && workspace, "bdv_bn_train_stats: null pointer");
+  BDV_REQUIRE(M > 0 && bn_c_ok(C), "bdv_bn_train_stats: unsupported M=%lld C=%d", (long long)M, C);
+  BDV_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bdv_bn_train_stats: running stats must come in pairs");
+  BDV_REQUIRE(bdv_aligned16(y) && bdv_aligned16(workspace), "bdv_bn_train_stats: alignment");
+  if (workspace_bytes < bdv_bn_workspace_bytes(M, C)) {
+    bdv_set_error("bdv_bn_train_stats: workspace too small");
+    return BDV_EWORKSPACE;
+  }
+  const BnGrid b = bn_grid(M, C);
+  float* psum = (float*)workspace;
+  float* psq = psum + MAX_RB_TIMES_C;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(b.RB, b.CC), dim3(256), 0, s, y, psum, psq, M, C, b.CVB, b.RL, b.rows_per_block);
+  BDV_LAUNCH_CHECK("bdv_bn_train_stats(partial)");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)psum, (const float*)psq, b.RB,
+                     M, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
+  BDV_LAUNCH_CHECK("bdv_bn_train_stats(finalize)");
+  return BDV_OK;
+}
+
+extern "C" int bdv_bn_eval_params(int C, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale, float* shift, void* stream) {
+  BDV_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bdv_bn_eval_params: bad argument");
+  hipLaunchKernelGGL(bn_eval_params_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
+                     running_mean, running_var, eps, scale, shift);
+  BDV_LAUNCH_CHECK("bdv_bn_eval_params");
+  return BDV_OK;
+}
+
+extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shift, const float* res, float* out, int64_t M,
+                            int C, int relu, void* stream) {
+  BDV_REQUIRE(y && scale && shift && out, "bdv_bn_apply: null pointer");
+  BDV_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bdv_bn_apply: bad shape");
+  BDV_REQUIRE(bdv_aligned16(y) && bdv_aligned16(out) && bdv_aligned16(scale) && bdv_aligned16(shift) &&
+                  (res == nullptr || bdv_aligned16(res)), "bdv_bn_apply: alignment");
+  const int64_t n4 = M * C / 4;
+  const int CV = C / 4;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(ew_grid(n4)), blk(256);
+  const float4 *y4 = (const float4*)y, *sc = (const float4*)scale, *sh = (const float4*)shift, *r4 = (const float4*)res;
+  float4* o4 = (float4*)out;
+  if (relu && res) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, blk, 0, s, y4, sc, sh, r4, o4, n4, CV);
+  else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, blk, 0, s, y4, sc, sh, r4, o4, n4, CV);
+  else if (res) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, blk, 0, s, y4, sc, sh, r4, o4, n4, CV);
+  else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, blk, 0, s, y4, sc, sh, r4, o4, n4, CV);
+  BDV_LAUNCH_CHECK("bdv_bn_apply");
+  return BDV_OK;
+}
+
+extern "C" int bdv_bn_backward(const float* dout, const float* out, const float* y, const float* gamma,
+                               const float* save_mean, const float* save_invstd, float* dy, float* dgamma, float* dbeta,
+                               float beta_acc, int64_t M, int C, int relu, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  BDV_REQUIRE(dout && y && gamma && save_mean && save_invstd && dy && workspace, "bdv_bn_backward: null pointer");
+  BDV_REQUIRE(!relu || out, "bdv_bn_backward: relu needs the forward output");
+  BDV_REQUIRE(M > 0 && bn_c_ok(C), "bdv_bn_backward: unsupported M=%lld C=%d", (long long)M, C);
+  BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(y) && bdv_aligned16(dy) && bdv_aligned16(workspace) &&
+                  bdv_aligned16(save_mean) && bdv_aligned16(save_invstd), "bdv_bn_backward: alignment");
+  if (workspace_bytes < bdv_bn_workspace_bytes(M, C)) {
+    bdv_set_error("bdv_bn_backward: workspace too small");
+    return BDV_EWORKSPACE;
+  }
+  const BnGrid b = bn_grid(M, C);
+  float* p1 = (float*)workspace;
+  float* p2 = p1 + MAX_RB_TIMES_C;
+  float* coef = p2 + MAX_RB_TIMES_C;
+  hipStream_t s = (hipStream_t)stream;
+  if (relu)
+    hipLaunchKernelGGL((bn_bwd_partial_kernel<true>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, out, y, save_mean, save_invstd,
+                       p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
+  else
+    hipLaunchKernelGGL((bn_bwd_partial_kernel<false>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, out, y, save_mean, save_invstd,
+                       p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
+  BDV_LAUNCH_CHECK("bdv_bn_backward(partial)");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)p1, (const float*)p2, b.RB,
+                     M, C, gamma, save_invstd, dgamma, dbeta, beta_acc, coef);
+  BDV_LAUNCH_CHECK("bdv_bn_backward(finalize)");
+  const int64_t n4 = M * C / 4;
+  const dim3 grid(ew_grid(n4)), blk(256);
+  if (relu)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), grid, blk, 0, s, (const float4*)dout, (const float4*)out, (const float4*)y,
+                       (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy, n4, C / 4);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, blk, 0, s, (const float4*)dout, (const float4*)out, (const float4*)y,
+                       (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy, n4, C / 4);
+  BDV_LAUNCH_CHECK("bdv_bn_backward(apply)");
+  return BDV_OK;
+}
+
+extern "C" int bdv_relu_bwd(const float* dout, const float* out, const float* add, float* g, int64_t numel, void* stream) {
+  BDV_REQUIRE(dout && out && g && numel > 0 && numel % 4 == 0, "bdv_relu_bwd: bad argument");
+  BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(out) && bdv_aligned16(g) && (!add || bdv_aligned16(add)), "bdv_relu_bwd: alignment");
+  const int64_t n4 = numel / 4;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout,
+                     (const float4*)out, (const float4*)add, (float4*)g, n4);
+  BDV_LAUNCH_CHECK("bdv_relu_bwd");
+  return BDV_OK;
+}
+
+extern "C" int bdv_add(const float* a, const float* b, float* out, int64_t numel, void* stream) {
+  BDV_REQUIRE(a && b && out && numel > 0 && numel % 4 == 0, "bdv_add: bad argument");
+  BDV_REQUIRE(bdv_aligned16(a) && bdv_aligned16(b) && bdv_aligned16(out), "bdv_add: alignment");
+  const int64_t n4 = numel / 4;
+  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b,
+                     (float4*)out, n4);
+  BDV_LAUNCH_CHECK("bdv_add");
+  return BDV_OK;
+}

@@ -1,0 +1,247 @@
+// HBM-bound helpers around the conv stack: layout change at the boundary, max/avg pooling, and
+// the fused background-mix + normalize front-end (uint8 in, NHWC4 fp32 out).
+#include "common.h"
+
+namespace {
+
+// (N,3,H,W) -> (N,H,W,4); one thread per pixel: three coalesced plane reads, one 16-byte store.
+__global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float4* __restrict__ out, int64_t npix,
+                                                              int HW) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+    const int64_t n = i / HW;
+    const int64_t p = i - n * HW;
+    const float* b = x + n * 3 * HW + p;
+    out[i] = make_float4(b[0], b[HW], b[2 * (int64_t)HW], 0.f);
+  }
+}
+
+// MaxPool2d(3, 2, 1) NHWC; thread = (output pixel, 4 channels).  First maximum in (r,s) scan order wins.
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ out,
+                                                           uchar4* __restrict__ idx, int N, int H, int W, int CV, int Ho, int Wo) {
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % CV);
+    int64_t pix = i / CV;
+    const int wo = (int)(pix % Wo);
+    pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uchar4 mi = make_uchar4(255, 255, 255, 255);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hi = 2 * ho - 1 + r;
+      if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int wi = 2 * wo - 1 + s;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const float4 v = x[((int64_t)(n * H + hi) * W + wi) * CV + c4];
+        const unsigned char t = (unsigned char)(r * 3 + s);
+        if (v.x > m.x || mi.x == 255) { m.x = v.x; mi.x = t; }
+        if (v.y > m.y || mi.y == 255) { m.y = v.y; mi.y = t; }
+        if (v.z > m.z || mi.z == 255) { m.z = v.z; mi.z = t; }
+        if (v.w > m.w || mi.w == 255) { m.w = v.w; mi.w = t; }
+      }
+    }
+    out[i] = m;
+    idx[i] = mi;
+  }
+}
+
+// gather form of the backward: input pixel (h,w) collects from the <= 2x2 windows that contain it
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restrict__ dout, const uchar4* __restrict__ idx,
+                                                           float4* __restrict__ dx, int N, int H, int W, int CV, int Ho, int Wo) {
+  const int64_t total = (int64_t)N * H * W * CV;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % CV);
+    int64_t pix = i / CV;
+    const int w = (int)(pix % W);
+    pix /= W;
+    const int h = (int)(pix % H);
+    const int n = (int)(pix / H);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hn = h + 1 - r;  // = 2*ho
+      if (hn < 0 || (hn & 1)) continue;
+      const int ho = hn >> 1;
+      if (ho >= Ho) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int wn = w + 1 - s;
+        if (wn < 0 || (wn & 1)) continue;
+        const int wo = wn >> 1;
+        if (wo >= Wo) continue;
+        const int64_t o = ((int64_t)(n * Ho + ho) * Wo + wo) * CV + c4;
+        const uchar4 t = idx[o];
+        const float4 d = dout[o];
+        const unsigned char me = (unsigned char)(r * 3 + s);
+        if (t.x == me) g.x += d.x;
+        if (t.y == me) g.y += d.y;
+        if (t.z == me) g.z += d.z;
+        if (t.w == me) g.w += d.w;
+      }
+    }
+    dx[i] = g;
+  }
+}
+
+// [N][HW][C] -> [N][C]
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ out, int N, int HW,
+                                                           int CV) {
+  const int64_t total = (int64_t)N * CV;
+  const float inv = 1.f / (float)HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % CV);
+    const int64_t n = i / CV;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < HW; ++p) {
+      const float4 v = x[(n * HW + p) * CV + c4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    out[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float4* __restrict__ dout, float4* __restrict__ dx, int N, int HW,
+                                                           int CV) {
+  const int64_t total = (int64_t)N * HW * CV;
+  const float inv = 1.f / (float)HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % CV);
+    const int64_t n = i / ((int64_t)HW * CV);
+    const float4 d = dout[n * CV + c4];
+    dx[i] = make_float4(d.x * inv, d.y * inv, d.z * inv, d.w * inv);
+  }
+}
+
+struct NormParams {
+  float mean[3], std[3], inv_std[3];
+  float alpha;
+};
+
+// Fused front-end.  One thread = one pixel of one clip position (b, h, w): the background pixel is
+// loaded and normalised once and reused for the T frames of the clip.
+__global__ __launch_bounds__(256) void bgmix_normalize_kernel(const uint8_t* __restrict__ frames, const uint8_t* __restrict__ bg,
+                                                               const uint8_t* __restrict__ mix, NormParams np,
+                                                               float4* __restrict__ out_nhwc4, float* __restrict__ out_nchw,
+                                                               int B, int T, int HW) {
+  const int64_t total = (int64_t)B * HW;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int b = (int)(i / HW);
+    const int p = (int)(i - (int64_t)b * HW);
+    const bool do_mix = mix != nullptr && mix[b] != 0;
+    float bgn[3] = {0.f, 0.f, 0.f};
+    if (do_mix) {
+      const uint8_t* q = bg + ((int64_t)b * HW + p) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) bgn[c] = __fdiv_rn(__fsub_rn((float)q[c], np.mean[c]), np.std[c]);
+    }
+    const float one_m_alpha = 1.f - np.alpha;
+    for (int t = 0; t < T; ++t) {
+      const int64_t f = (int64_t)b * T + t;
+      const uint8_t* q = frames + (f * HW + p) * 3;
+      float v[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float xn = __fmul_rn(__fsub_rn((float)q[c], np.mean[c]), np.inv_std[c]);
+        if (do_mix) xn = __fadd_rn(__fmul_rn(xn, one_m_alpha), __fmul_rn(bgn[c], np.alpha));
+        v[c] = xn;
+      }
+      if (out_nhwc4 != nullptr) out_nhwc4[f * HW + p] = make_float4(v[0], v[1], v[2], 0.f);
+      if (out_nchw != nullptr) {
+        float* o = out_nchw + f * 3 * HW + p;
+        o[0] = v[0];
+        o[HW] = v[1];
+        o[2 * (int64_t)HW] = v[2];
+      }
+    }
+  }
+}
+
+int ew_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int bdv_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream) {
+  BDV_REQUIRE(x && out && N > 0 && H > 0 && W > 0, "bdv_nchw3_to_nhwc4: bad argument");
+  BDV_REQUIRE(bdv_aligned16(out), "bdv_nchw3_to_nhwc4: alignment");
+  const int64_t npix = (int64_t)N * H * W;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(ew_grid(npix)), dim3(256), 0, (hipStream_t)stream, x, (float4*)out, npix, H * W);
+  BDV_LAUNCH_CHECK("bdv_nchw3_to_nhwc4");
+  return BDV_OK;
+}
+
+extern "C" int bdv_maxpool_fwd(const float* x, float* out, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+  BDV_REQUIRE(x && out && idx && N > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, "bdv_maxpool_fwd: bad argument");
+  BDV_REQUIRE(bdv_aligned16(x) && bdv_aligned16(out) && (((uintptr_t)idx) & 3) == 0, "bdv_maxpool_fwd: alignment");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)out,
+                     (uchar4*)idx, N, H, W, C / 4, Ho, Wo);
+  BDV_LAUNCH_CHECK("bdv_maxpool_fwd");
+  return BDV_OK;
+}
+
+extern "C" int bdv_maxpool_bwd(const float* dout, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream) {
+  BDV_REQUIRE(dout && dx && idx && N > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, "bdv_maxpool_bwd: bad argument");
+  BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(dx) && (((uintptr_t)idx) & 3) == 0, "bdv_maxpool_bwd: alignment");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)N * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout,
+                     (const uchar4*)idx, (float4*)dx, N, H, W, C / 4, Ho, Wo);
+  BDV_LAUNCH_CHECK("bdv_maxpool_bwd");
+  return BDV_OK;
+}
+
+extern "C" int bdv_avgpool_fwd(const float* x, float* out, int N, int HW, int C, void* stream) {
+  BDV_REQUIRE(x && out && N > 0 && HW > 0 && C > 0 && C % 4 == 0, "bdv_avgpool_fwd: bad argument");
+  BDV_REQUIRE(bdv_aligned16(x) && bdv_aligned16(out), "bdv_avgpool_fwd: alignment");
+  const int64_t total = (int64_t)N * (C / 4);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)out, N,
+                     HW, C / 4);
+  BDV_LAUNCH_CHECK("bdv_avgpool_fwd");
+  return BDV_OK;
+}
+
+extern "C" int bdv_avgpool_bwd(const float* dout, float* dx, int N, int HW, int C, void* stream) {
+  BDV_REQUIRE(dout && dx && N > 0 && HW > 0 && C > 0 && C % 4 == 0, "bdv_avgpool_bwd: bad argument");
+  BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(dx), "bdv_avgpool_bwd: alignment");
+  const int64_t total = (int64_t)N * HW * (C / 4);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout, (float4*)dx,
+                     N, HW, C / 4);
+  BDV_LAUNCH_CHECK("bdv_avgpool_bwd");
+  return BDV_OK;
+}
+
+extern "C" int bdv_bgmix_normalize_u8(const uint8_t* frames, const uint8_t* bg, const uint8_t* mix, float alpha,
+                                      const float mean[3], const float std[3], const float inv_std[3], float* out_nhwc4,
+                                      float* out_nchw, int B, int T, int H, int W, void* stream) {
+  BDV_REQUIRE(frames && mean && std && inv_std, "bdv_bgmix_normalize_u8: null pointer");
+  BDV_REQUIRE((bg == nullptr) == (mix == nullptr), "bdv_bgmix_normalize_u8: bg and mix come together");
+  BDV_REQUIRE(out_nhwc4 || out_nchw, "bdv_bgmix_normalize_u8: no output requested");
+  BDV_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0, "bdv_bgmix_normalize_u8: bad shape");
+  BDV_REQUIRE(out_nhwc4 == nullptr || bdv_aligned16(out_nhwc4), "bdv_bgmix_normalize_u8: alignment");
+  NormParams np;
+  for (int c = 0; c < 3; ++c) {
+    np.mean[c] = mean[c];
+    np.std[c] = std[c];
+    np.inv_std[c] = inv_std[c];
+  }
+  np.alpha = alpha;
+  const int64_t total = (int64_t)B * H * W;
+  hipLaunchKernelGGL(bgmix_normalize_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, frames, bg, mix, np,
+                     (float4*)out_nhwc4, out_nchw, B, T, H * W);
+  BDV_LAUNCH_CHECK("bdv_bgmix_normalize_u8");
+  return BDV_OK;
+}

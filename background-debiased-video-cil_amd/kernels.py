@@ -1,0 +1,473 @@
+"""Tensor-level wrappers over the C ABI: shape/dtype/device checks on the host, then a launch on
+torch's current HIP stream.  PyTorch is only the owner of device memory and streams here.
+
+Every wrapper validates that operand shapes match what the kernel grid assumes BEFORE launching
+(an out-of-bounds access on the GPU can reset the whole node).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import ConvGeom, check, lib
+
+_WS = {}  # (device index, tag) -> workspace tensor (grown on demand, never shrunk)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(t: torch.Tensor, shape: Optional[Sequence[int]] = None, dtype=torch.float32, name='tensor'):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name}: expected a tensor, got {type(t)}')
+    if not t.is_cuda:
+        raise RuntimeError(f'{name}: the HIP path needs a GPU tensor (got device {t.device}); there is no CPU fallback')
+    if t.dtype != dtype:
+        raise TypeError(f'{name}: dtype {t.dtype}, expected {dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name}: must be contiguous, got strides {t.stride()} for shape {tuple(t.shape)}')
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f'{name}: shape {tuple(t.shape)}, expected {tuple(shape)}')
+    return t
+
+
+def workspace(nbytes: int, device, tag='ws') -> torch.Tensor:
+    key = (torch.device(device).index or 0, tag)
+    cur = _WS.get(key)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = cur
+    return cur
+
+
+def make_geom(N, H, W, Cin, Cout, R, S, stride, pad, T=1, fold=0) -> ConvGeom:
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - S) // stride + 1
+    return ConvGeom(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, T, fold)
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------------------------
+
+def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (N,H,W,Cin) NHWC, w (Cout,R,S,Cin) -> y (N,Ho,Wo,Cout)."""
+    _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
+    _chk(w, (g.Cout, g.R, g.S, g.Cin), name='w')
+    y = out if out is not None else torch.empty((g.N, g.Ho, g.Wo, g.Cout), dtype=torch.float32, device=x.device)
+    _chk(y, (g.N, g.Ho, g.Wo, g.Cout), name='y')
+    check(lib().bdv_conv_fprop(_p(x), _p(w), _p(y), ctypes.byref(g), _stream()), 'bdv_conv_fprop')
+    return y
+
+
+def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional[torch.Tensor] = None,
+               add_mask_src: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
+    _chk(w, (g.Cout, g.R, g.S, g.Cin), name='w')
+    dx = out if out is not None else torch.empty((g.N, g.H, g.W, g.Cin), dtype=torch.float32, device=dy.device)
+    _chk(dx, (g.N, g.H, g.W, g.Cin), name='dx')
+    if add_src is not None:
+        _chk(add_src, (g.N, g.H, g.W, g.Cin), name='add_src')
+        if add_src.data_ptr() == dx.data_ptr() and g.fold > 0:
+            raise ValueError('conv_dgrad: in-place add_src is not allowed with a temporal shift (scatter epilogue)')
+    if add_mask_src is not None:
+        _chk(add_mask_src, (g.N, g.H, g.W, g.Cin), name='add_mask_src')
+    check(lib().bdv_conv_dgrad(_p(dy), _p(w), _p(dx), _p(add_src), _p(add_mask_src), ctypes.byref(g), _stream()),
+          'bdv_conv_dgrad')
+    return dx
+
+
+def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, dw: Optional[torch.Tensor] = None,
+               beta: float = 0.0) -> torch.Tensor:
+    _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
+    _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
+    if dw is None:
+        dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
+        beta = 0.0
+    _chk(dw, (g.Cout, g.R, g.S, g.Cin), name='dw')
+    need = lib().bdv_conv_wgrad_workspace_bytes(ctypes.byref(g))
+    if need == 0:
+        check(-1, 'bdv_conv_wgrad_workspace_bytes')
+    ws = workspace(need, dy.device, 'wgrad')
+    check(lib().bdv_conv_wgrad(_p(dy), _p(x), _p(dw), float(beta), ctypes.byref(g), _p(ws), ws.numel(), _stream()),
+          'bdv_conv_wgrad')
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# batch norm (+ReLU, +residual)
+# ---------------------------------------------------------------------------------------------
+
+def _bn_ws(M, C, device):
+    return workspace(lib().bdv_bn_workspace_bytes(int(M), int(C)), device, 'bn')
+
+
+def bn_train_stats(y, gamma, beta, eps, momentum, running_mean, running_var):
+    """y (..., C) -> (save_mean, save_invstd, scale, shift); running stats updated in place."""
+    C = y.shape[-1]
+    M = y.numel() // C
+    _chk(y, name='y')
+    for t, n in ((gamma, 'gamma'), (beta, 'beta')):
+        _chk(t, (C,), name=n)
+    if running_mean is not None:
+        _chk(running_mean, (C,), name='running_mean')
+        _chk(running_var, (C,), name='running_var')
+    stats = torch.empty((4, C), dtype=torch.float32, device=y.device)
+    ws = _bn_ws(M, C, y.device)
+    check(lib().bdv_bn_train_stats(_p(y), M, C, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
+                                   _p(running_var), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), _p(ws),
+                                   ws.numel(), _stream()), 'bdv_bn_train_stats')
+    return stats[0], stats[1], stats[2], stats[3]
+
+
+def bn_eval_params(gamma, beta, running_mean, running_var, eps):
+    C = gamma.numel()
+    for t, n in ((gamma, 'gamma'), (beta, 'beta'), (running_mean, 'running_mean'), (running_var, 'running_var')):
+        _chk(t, (C,), name=n)
+    ss = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
+    check(lib().bdv_bn_eval_params(C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), _p(ss[0]),
+                                   _p(ss[1]), _stream()), 'bdv_bn_eval_params')
+    return ss[0], ss[1]
+
+
+def bn_apply(y, scale, shift, res=None, relu=True, out=None):
+    C = y.shape[-1]
+    M = y.numel() // C
+    _chk(y, name='y')
+    _chk(scale, (C,), name='scale')
+    _chk(shift, (C,), name='shift')
+    if res is not None:
+        _chk(res, tuple(y.shape), name='res')
+    o = out if out is not None else torch.empty_like(y)
+    _chk(o, tuple(y.shape), name='out')
+    check(lib().bdv_bn_apply(_p(y), _p(scale), _p(shift), _p(res), _p(o), M, C, int(bool(relu)), _stream()), 'bdv_bn_apply')
+    return o
+
+
+def bn_backward(dout, out, y, gamma, save_mean, save_invstd, relu, dgamma=None, dbeta=None, beta_acc=0.0, dy=None):
+    """Returns (dy, dgamma, dbeta).  ``out`` is the forward output (needed only when relu)."""
+    C = y.shape[-1]
+    M = y.numel() // C
+    _chk(dout, tuple(y.shape), name='dout')
+    _chk(y, name='y')
+    if relu:
+        _chk(out, tuple(y.shape), name='out')
+    for t, n in ((gamma, 'gamma'), (save_mean, 'save_mean'), (save_invstd, 'save_invstd')):
+        _chk(t, (C,), name=n)
+    if dgamma is None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
+        beta_acc = 0.0
+    _chk(dgamma, (C,), name='dgamma')
+    _chk(dbeta, (C,), name='dbeta')
+    d = dy if dy is not None else torch.empty_like(y)
+    _chk(d, tuple(y.shape), name='dy')
+    ws = _bn_ws(M, C, y.device)
+    check(lib().bdv_bn_backward(_p(dout), _p(out if relu else None), _p(y), _p(gamma), _p(save_mean), _p(save_invstd),
+                                _p(d), _p(dgamma), _p(dbeta), float(beta_acc), M, C, int(bool(relu)), _p(ws), ws.numel(),
+                                _stream()), 'bdv_bn_backward')
+    return d, dgamma, dbeta
+
+
+def relu_bwd(dout, out, add=None, g=None):
+    _chk(dout, name='dout')
+    _chk(out, tuple(dout.shape), name='out')
+    if add is not None:
+        _chk(add, tuple(dout.shape), name='add')
+    r = g if g is not None else torch.empty_like(dout)
+    _chk(r, tuple(dout.shape), name='g')
+    check(lib().bdv_relu_bwd(_p(dout), _p(out), _p(add), _p(r), dout.numel(), _stream()), 'bdv_relu_bwd')
+    return r
+
+
+def add(a, b, out=None):
+    _chk(a, name='a')
+    _chk(b, tuple(a.shape), name='b')
+    o = out if out is not None else torch.empty_like(a)
+    _chk(o, tuple(a.shape), name='out')
+    check(lib().bdv_add(_p(a), _p(b), _p(o), a.numel(), _stream()), 'bdv_add')
+    return o
+
+
+# ---------------------------------------------------------------------------------------------
+# stem helpers / pooling / front-end
+# ---------------------------------------------------------------------------------------------
+
+def nchw3_to_nhwc4(x):
+    """(N,3,H,W) -> (N,H,W,4)."""
+    _chk(x, name='x')
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f'nchw3_to_nhwc4: expected (N,3,H,W), got {tuple(x.shape)}')
+    N, _, H, W = x.shape
+    out = torch.empty((N, H, W, 4), dtype=torch.float32, device=x.device)
+    check(lib().bdv_nchw3_to_nhwc4(_p(x), _p(out), N, H, W, _stream()), 'bdv_nchw3_to_nhwc4')
+    return out
+
+
+def maxpool_fwd(x):
+    _chk(x, name='x')
+    N, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    check(lib().bdv_maxpool_fwd(_p(x), _p(out), _p(idx), N, H, W, C, _stream()), 'bdv_maxpool_fwd')
+    return out, idx
+
+
+def maxpool_bwd(dout, idx, in_shape):
+    N, H, W, C = in_shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    _chk(dout, (N, Ho, Wo, C), name='dout')
+    _chk(idx, (N, Ho, Wo, C), dtype=torch.uint8, name='idx')
+    dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dout.device)
+    check(lib().bdv_maxpool_bwd(_p(dout), _p(idx), _p(dx), N, H, W, C, _stream()), 'bdv_maxpool_bwd')
+    return dx
+
+
+def avgpool_fwd(x):
+    _chk(x, name='x')
+    N, H, W, C = x.shape
+    out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    check(lib().bdv_avgpool_fwd(_p(x), _p(out), N, H * W, C, _stream()), 'bdv_avgpool_fwd')
+    return out
+
+
+def avgpool_bwd(dout, in_shape):
+    N, H, W, C = in_shape
+    _chk(dout, (N, C), name='dout')
+    dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dout.device)
+    check(lib().bdv_avgpool_bwd(_p(dout), _p(dx), N, H * W, C, _stream()), 'bdv_avgpool_bwd')
+    return dx
+
+
+def bgmix_normalize_u8(frames, bg, mix, alpha, mean, std, want_nhwc4=True, want_nchw=False):
+    """frames (B,T,H,W,3) u8, bg (B,H,W,3) u8 | None, mix (B,) u8/bool | None."""
+    _chk(frames, dtype=torch.uint8, name='frames')
+    B, T, H, W, c3 = frames.shape
+    if c3 != 3:
+        raise ValueError('frames must be (B,T,H,W,3)')
+    if bg is not None:
+        _chk(bg, (B, H, W, 3), dtype=torch.uint8, name='bg')
+        mix = mix.to(torch.uint8) if mix.dtype != torch.uint8 else mix
+        _chk(mix, (B,), dtype=torch.uint8, name='mix')
+    else:
+        mix = None
+    f3 = ctypes.c_float * 3
+    m = torch.tensor(list(mean), dtype=torch.float32)
+    s = torch.tensor(list(std), dtype=torch.float32)
+    inv = 1.0 / s      # fp32 reciprocal, as the CPU restatement computes it
+    o4 = torch.empty((B * T, H, W, 4), dtype=torch.float32, device=frames.device) if want_nhwc4 else None
+    oc = torch.empty((B, T, 3, H, W), dtype=torch.float32, device=frames.device) if want_nchw else None
+    check(lib().bdv_bgmix_normalize_u8(_p(frames), _p(bg), _p(mix), float(alpha), f3(*m.tolist()), f3(*s.tolist()),
+                                       f3(*inv.tolist()), _p(o4), _p(oc), B, T, H, W, _stream()), 'bdv_bgmix_normalize_u8')
+    return o4, oc
+
+
+# ---------------------------------------------------------------------------------------------
+# heads / losses
+# ---------------------------------------------------------------------------------------------
+
+def lsc_fwd(x, w, K, P):
+    _chk(x, name='x')
+    N, D = x.shape
+    _chk(w, (K, P * D), name='w')
+    sim = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    xnorm = torch.empty(N, dtype=torch.float32, device=x.device)
+    wnorm = torch.empty(K * P, dtype=torch.float32, device=x.device)
+    cosbuf = torch.empty((N, K * P), dtype=torch.float32, device=x.device)
+    check(lib().bdv_lsc_fwd(_p(x), _p(w), _p(sim), _p(xnorm), _p(wnorm), _p(cosbuf), N, D, K, P, _stream()), 'bdv_lsc_fwd')
+    return sim, xnorm, wnorm, cosbuf
+
+
+def lsc_bwd(dsim, x, w, xnorm, wnorm, cosbuf, K, P, need_dw=True, dw=None, beta_w=0.0):
+    N, D = x.shape
+    _chk(dsim, (N, K), name='dsim')
+    _chk(x, name='x')
+    _chk(w, (K, P * D), name='w')
+    _chk(xnorm, (N,), name='xnorm')
+    _chk(wnorm, (K * P,), name='wnorm')
+    _chk(cosbuf, (N, K * P), name='cosbuf')
+    dx = torch.empty_like(x)
+    if need_dw and dw is None:
+        dw = torch.empty_like(w)
+        beta_w = 0.0
+    if dw is not None:
+        _chk(dw, (K, P * D), name='dw')
+    ws = torch.empty((N, K * P), dtype=torch.float32, device=x.device)
+    check(lib().bdv_lsc_bwd(_p(dsim), _p(x), _p(w), _p(xnorm), _p(wnorm), _p(cosbuf), _p(dx), _p(dw if need_dw else None),
+                            float(beta_w), _p(ws), N, D, K, P, _stream()), 'bdv_lsc_bwd')
+    return dx, (dw if need_dw else None)
+
+
+def linear_fwd(x, w, b):
+    _chk(x, name='x')
+    N, D = x.shape
+    K = w.shape[0]
+    _chk(w, (K, D), name='w')
+    if b is not None:
+        _chk(b, (K,), name='b')
+    out = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    check(lib().bdv_linear_fwd(_p(x), _p(w), _p(b), _p(out), N, D, K, _stream()), 'bdv_linear_fwd')
+    return out
+
+
+def linear_bwd(dout, x, w, need_dx=True, need_dw=True, need_db=True, dw=None, db=None, beta_w=0.0):
+    N, D = x.shape
+    K = w.shape[0]
+    _chk(dout, (N, K), name='dout')
+    _chk(x, name='x')
+    _chk(w, (K, D), name='w')
+    dx = torch.empty_like(x) if need_dx else None
+    if need_dw and dw is None:
+        dw = torch.empty_like(w)
+        db = torch.empty(K, dtype=torch.float32, device=x.device) if need_db else None
+        beta_w = 0.0
+    if need_dw:
+        _chk(dw, (K, D), name='dw')
+        if db is not None:
+            _chk(db, (K,), name='db')
+    check(lib().bdv_linear_bwd(_p(dout), _p(x), _p(w), _p(dx), _p(dw if need_dw else None), _p(db if need_dw else None),
+                               float(beta_w), N, D, K, _stream()), 'bdv_linear_bwd')
+    return dx, (dw if need_dw else None), (db if need_dw else None)
+
+
+def consensus_fwd(s, B, T):
+    _chk(s, name='s')
+    K = s.shape[1]
+    if s.shape[0] != B * T:
+        raise ValueError(f'consensus_fwd: {s.shape[0]} rows != B*T = {B * T}')
+    out = torch.empty((B, K), dtype=torch.float32, device=s.device)
+    check(lib().bdv_consensus_fwd(_p(s), _p(out), B, T, K, _stream()), 'bdv_consensus_fwd')
+    return out
+
+
+def consensus_bwd(dout, T):
+    _chk(dout, name='dout')
+    B, K = dout.shape
+    ds = torch.empty((B * T, K), dtype=torch.float32, device=dout.device)
+    check(lib().bdv_consensus_bwd(_p(dout), _p(ds), B, T, K, _stream()), 'bdv_consensus_bwd')
+    return ds
+
+
+def dropout(x, p, seed):
+    _chk(x, name='x')
+    out = torch.empty_like(x)
+    check(lib().bdv_dropout(_p(x), _p(out), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()), 'bdv_dropout')
+    return out
+
+
+def lsc_loss(sim, targets, eta, margin, hinge):
+    _chk(sim, name='sim')
+    B, K = sim.shape
+    _chk(targets, (B,), dtype=torch.int64, name='targets')
+    _chk(eta, (1,), name='eta')
+    out = torch.empty(2, dtype=torch.float32, device=sim.device)   # loss, deta
+    dsim = torch.empty_like(sim)
+    check(lib().bdv_lsc_loss(_p(sim), _p(targets), _p(eta), float(margin), int(bool(hinge)), _p(out[0:1]), _p(dsim),
+                             _p(out[1:2]), B, K, _stream()), 'bdv_lsc_loss')
+    return out[0], dsim, out[1:2]
+
+
+def softce_loss(score, soft_targets=None, labels=None):
+    _chk(score, name='score')
+    B, K = score.shape
+    if soft_targets is not None:
+        _chk(soft_targets, (B, K), name='soft_targets')
+    else:
+        _chk(labels, (B,), dtype=torch.int64, name='labels')
+    loss = torch.empty(1, dtype=torch.float32, device=score.device)
+    dscore = torch.empty_like(score)
+    check(lib().bdv_softce_loss(_p(score), _p(soft_targets), _p(labels), _p(loss), _p(dscore), B, K, _stream()),
+          'bdv_softce_loss')
+    return loss[0], dscore
+
+
+def icarl_targets(labels, prev_logits, prev_K, K):
+    B = labels.numel()
+    labels = labels.reshape(B)
+    _chk(labels, (B,), dtype=torch.int64, name='labels')
+    if prev_logits is not None:
+        _chk(prev_logits, (B, K), name='prev_logits')
+    tgt = torch.empty((B, K), dtype=torch.float32, device=labels.device)
+    check(lib().bdv_icarl_targets(_p(labels), _p(prev_logits), int(prev_K), _p(tgt), B, K, _stream()), 'bdv_icarl_targets')
+    return tgt
+
+
+def softmax_mean(s, B, n, apply_softmax=True):
+    _chk(s, name='s')
+    K = s.shape[1]
+    if s.shape[0] != B * n:
+        raise ValueError('softmax_mean: row count mismatch')
+    out = torch.empty((B, K), dtype=torch.float32, device=s.device)
+    check(lib().bdv_softmax_mean(_p(s), _p(out), B, n, K, int(bool(apply_softmax)), _stream()), 'bdv_softmax_mean')
+    return out
+
+
+def topk_acc(score, labels):
+    _chk(score, name='score')
+    B, K = score.shape
+    _chk(labels, (B,), dtype=torch.int64, name='labels')
+    acc = torch.empty(2, dtype=torch.float32, device=score.device)
+    check(lib().bdv_topk_acc(_p(score), _p(labels), _p(acc), B, K, _stream()), 'bdv_topk_acc')
+    return acc
+
+
+def kd_mse_fwd(cur, prev):
+    """cur/prev: any same-shape, same-stride dense tensors (compared in storage order)."""
+    if cur.shape != prev.shape or cur.stride() != prev.stride():
+        raise ValueError('kd_mse: cur and prev need identical shape and strides')
+    a, b = _dense_storage(cur), _dense_storage(prev)
+    mse = torch.empty(1, dtype=torch.float32, device=cur.device)
+    ws = workspace(lib().bdv_reduce_workspace_bytes(), cur.device, 'red')
+    check(lib().bdv_kd_mse_fwd(_p(a), _p(b), _p(mse), a.numel(), _p(ws), ws.numel(), _stream()), 'bdv_kd_mse_fwd')
+    return mse[0]
+
+
+def kd_mse_bwd(cur, prev, gscale_dev, gscale_host=1.0):
+    a, b = _dense_storage(cur), _dense_storage(prev)
+    d = torch.empty_like(cur)        # preserves strides for dense tensors
+    if d.stride() != cur.stride():
+        raise ValueError('kd_mse_bwd: could not preserve strides')
+    if gscale_dev is not None:
+        _chk(gscale_dev.reshape(1), (1,), name='gscale')
+    check(lib().bdv_kd_mse_bwd(_p(a), _p(b), _p(gscale_dev), float(gscale_host), _p(_dense_storage(d)), a.numel(), _stream()),
+          'bdv_kd_mse_bwd')
+    return d
+
+
+def _dense_storage(t: torch.Tensor) -> torch.Tensor:
+    """Flat view over the storage of a dense (possibly permuted) tensor."""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError('expected an fp32 GPU tensor; there is no CPU fallback')
+    if t.is_contiguous():
+        return t.reshape(-1)
+    order = sorted(range(t.dim()), key=lambda i: -t.stride(i))
+    p = t.permute(order)
+    if not p.is_contiguous():
+        raise ValueError('tensor is not dense')
+    return p.reshape(-1)
+
+
+# ---------------------------------------------------------------------------------------------
+# optimizer
+# ---------------------------------------------------------------------------------------------
+
+def multi_sqnorm(grad_ptrs, numels, ntensors, out):
+    ws = workspace(ntensors * 32 * 4, out.device, 'sqn')
+    check(lib().bdv_multi_sqnorm(_p(grad_ptrs), _p(numels), ntensors, _p(out), _p(ws), ws.numel(), _stream()), 'bdv_multi_sqnorm')
+
+
+def clip_coef(sqnorm, grad_scale, max_norm, coef):
+    check(lib().bdv_clip_coef(_p(sqnorm), float(grad_scale), float(max_norm), _p(coef), _stream()), 'bdv_clip_coef')
+
+
+def multi_sgd(param_ptrs, grad_ptrs, buf_ptrs, numels, lrs, wds, ntensors, momentum, grad_scale, coef):
+    check(lib().bdv_multi_sgd(_p(param_ptrs), _p(grad_ptrs), _p(buf_ptrs), _p(numels), _p(lrs), _p(wds), ntensors,
+                              float(momentum), float(grad_scale), _p(coef), _stream()), 'bdv_multi_sgd')

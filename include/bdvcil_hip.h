@@ -1,0 +1,178 @@
+/*
+ * bdvcil_hip.h -- C ABI of libbdvcil_hip.so: MI355X (gfx950) kernels for the TSM
+ * class-incremental training hot path of NinV/Background-Debiased-Video-CIL.
+ *
+ * The reference has NO FFI for this path: its hot path is `mmaction.models` Python executed by
+ * PyTorch/cuDNN.  Each entry point below therefore names the reference
+ * call site (file:line under /root/reference, or UPSTREAM mmaction2 0.24 / torch op) whose
+ * arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative BDV_E* code for argument errors or a positive
+ *     hipError_t for launch errors; nothing throws; bdv_last_error() gives a thread-local message.
+ *   - the caller owns every buffer (incl. workspaces); pointers are device pointers unless noted;
+ *     kernels are enqueued on `stream` (a hipStream_t passed as void*) and never synchronise.
+ *   - no global mutable state: re-entrant, thread-safe, hipGraph-capturable.
+ *   - activations are fp32 NHWC: [N][H][W][C], N = clips * segments (frames), C % 4 == 0,
+ *     16-byte aligned.  Conv weights are [Cout][R][S][Cin] (the storage of a torch
+ *     channels_last OIHW tensor).  All arithmetic is fp32 (f32-input MFMA, exact fp32 FMA chains).
+ */
+#ifndef BDVCIL_HIP_H
+#define BDVCIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDV_OK 0
+#define BDV_EINVAL (-1)   /* bad shape / alignment / null pointer */
+#define BDV_EWORKSPACE (-2) /* workspace too small */
+
+/* Geometry of one 2-D convolution site (UPSTREAM mmaction ResNet ConvModule.conv). */
+typedef struct bdv_conv_geom {
+  int32_t N;      /* frames = clips * T */
+  int32_t H, W;   /* input spatial size */
+  int32_t Cin;    /* input channels, multiple of 4 */
+  int32_t Ho, Wo; /* output spatial size */
+  int32_t Cout;   /* output channels, multiple of 64 */
+  int32_t R, S;   /* filter size */
+  int32_t stride; /* 1 or 2 */
+  int32_t pad;
+  int32_t T;      /* num_segments (frames per clip); used only when fold > 0 */
+  int32_t fold;   /* temporal-shift fold = Cin / shift_div, multiple of 4; 0 = no shift */
+} bdv_conv_geom;
+
+const char* bdv_last_error(void);
+int bdv_abi_version(void);
+
+/* ---- convolution = implicit GEMM on v_mfma_f32_32x32x2_f32 --------------------------------
+ * fprop replaces F.conv2d inside ConvModule (+ UPSTREAM TemporalShift.shift when fold > 0:
+ * channels [0,fold) read frame t+1, [fold,2fold) read frame t-1, zero at clip ends).
+ * x [N,H,W,Cin], w [Cout,R,S,Cin], y [N,Ho,Wo,Cout]. */
+int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* g, void* stream);
+
+/* dgrad: dx[N,H,W,Cin] = unshift(conv_transpose(dy, w)) + (add_src ? add_src * mask : 0),
+ * mask = (add_mask_src > 0) when add_mask_src != NULL (fused ReLU-backward of the identity path).
+ * Replaces autograd of F.conv2d w.r.t. its input and of TemporalShift.shift. */
+int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const float* add_src,
+                   const float* add_mask_src, const bdv_conv_geom* g, void* stream);
+
+/* wgrad: dw[Cout,R,S,Cin] = beta * dw + sum_pixels dy (x) shift(x).  Deterministic split-K:
+ * partial slabs go to `workspace`, a second kernel reduces them in fixed order. */
+size_t bdv_conv_wgrad_workspace_bytes(const bdv_conv_geom* g);
+int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float beta, const bdv_conv_geom* g,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- BatchNorm2d (train + eval), fused with ReLU / residual add --------------------------
+ * Replaces UPSTREAM ConvModule.bn (+ .activate, + block `out + identity`) and their autograd.
+ * y is [M][C] (M = N*Ho*Wo). */
+size_t bdv_bn_workspace_bytes(int64_t M, int C);
+/* train: batch mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale; saves mean and
+ * invstd; running_mean/var updated with `momentum` (unbiased var), num_batches_tracked handled by
+ * the caller. */
+int bdv_bn_train_stats(const float* y, int64_t M, int C, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var,
+                       float* save_mean, float* save_invstd, float* scale, float* shift,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* eval: scale/shift from running statistics. */
+int bdv_bn_eval_params(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* out = act(y*scale[c] + shift[c] + (res ? res : 0)), act = ReLU if relu != 0. */
+int bdv_bn_apply(const float* y, const float* scale, const float* shift, const float* res, float* out,
+                 int64_t M, int C, int relu, void* stream);
+/* backward of (BN-train -> +res -> ReLU): g = dout * (out > 0 if relu), dgamma = sum g*xhat,
+ * dbeta = sum g, dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).  dgamma/dbeta are written as
+ * beta_acc*old + new.  The residual-path gradient is g itself; consumers re-derive it from
+ * (dout, out) -- see bdv_conv_dgrad(add_src, add_mask_src) and bdv_relu_bwd. */
+int bdv_bn_backward(const float* dout, const float* out, const float* y, const float* gamma,
+                    const float* save_mean, const float* save_invstd, float* dy, float* dgamma,
+                    float* dbeta, float beta_acc, int64_t M, int C, int relu, void* workspace,
+                    size_t workspace_bytes, void* stream);
+/* g = dout * (out > 0) (+ add) : masked gradient for an identity path that has no conv behind it */
+int bdv_relu_bwd(const float* dout, const float* out, const float* add, float* g, int64_t numel, void* stream);
+/* out = a + b (gradient junctions) */
+int bdv_add(const float* a, const float* b, float* out, int64_t numel, void* stream);
+
+/* ---- stem helpers ------------------------------------------------------------------------ */
+/* (N,3,H,W) fp32 -> (N,H,W,4) fp32, 4th channel 0: boundary layout change for the NCHW batch
+ * the reference hands over (libs/cil/cil.py:514-516). */
+int bdv_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream);
+/* UPSTREAM ResNet.maxpool: MaxPool2d(3, stride 2, pad 1) on NHWC; idx holds the winning tap (0..8)
+ * per output element (first maximum in scan order, as torch). */
+int bdv_maxpool_fwd(const float* x, float* out, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int bdv_maxpool_bwd(const float* dout, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream);
+/* UPSTREAM TSMHead.avg_pool = AdaptiveAvgPool2d(1): [N,HW,C] -> [N,C] */
+int bdv_avgpool_fwd(const float* x, float* out, int N, int HW, int C, void* stream);
+int bdv_avgpool_bwd(const float* dout, float* dx, int N, int HW, int C, void* stream);
+
+/* ---- fused background-mix / normalize front-end -------------------------------------------
+ * libs/loader/comix_loader.py:72-75,138-145 + UPSTREAM Normalize (img_norm_cfg, config :121-122).
+ * frames (B,T,H,W,3) uint8 RGB, bg (B,H,W,3) uint8, mix (B) uint8 {0,1};
+ * out_nhwc4 (B*T,H,W,4) and/or out_nchw (B,T,3,H,W) (either may be NULL).
+ * frame: (x-mean)*inv_std ; bg: (x-mean)/std ; blend x*(1-alpha)+bg*alpha where mix[b] != 0. */
+int bdv_bgmix_normalize_u8(const uint8_t* frames, const uint8_t* bg, const uint8_t* mix, float alpha,
+                           const float mean[3], const float std[3], const float inv_std[3],
+                           float* out_nhwc4, float* out_nchw, int B, int T, int H, int W, void* stream);
+
+/* ---- classifier heads ---------------------------------------------------------------------- */
+/* libs/models/cil_heads/cosine_linear.py:27-43 (LSC): sim[n,k] = sum_p softmax_p(c)[p]*c[p],
+ * c[p] = cos(x_n, w_{k,p}) with torch>=2 eps semantics (each norm clamped at 1e-8).
+ * x (N,D), w (K,P*D), sim (N,K); xnorm (N), wnorm (K*P), cosbuf (N,K*P) are saved for backward. */
+int bdv_lsc_fwd(const float* x, const float* w, float* sim, float* xnorm, float* wnorm, float* cosbuf,
+                int N, int D, int K, int P, void* stream);
+int bdv_lsc_bwd(const float* dsim, const float* x, const float* w, const float* xnorm, const float* wnorm,
+                const float* cosbuf, float* dx, float* dw, float beta_w, float* dcos_ws,
+                int N, int D, int K, int P, void* stream);
+/* libs/models/cil_heads/inc_net.py:36-37 (IncrementalNet): out = x W^T + b */
+int bdv_linear_fwd(const float* x, const float* w, const float* b, float* out, int N, int D, int K, void* stream);
+int bdv_linear_bwd(const float* dout, const float* x, const float* w, float* dx, float* dw, float* db,
+                   float beta_w, int N, int D, int K, void* stream);
+/* UPSTREAM AvgConsensus(dim=1): (B*T,K) -> (B,K) mean over T, and its backward */
+int bdv_consensus_fwd(const float* s, float* out, int B, int T, int K, void* stream);
+int bdv_consensus_bwd(const float* dout, float* ds, int B, int T, int K, void* stream);
+/* UPSTREAM TSMHead.dropout: mask from a counter-based hash of (seed, element index); same call
+ * with the same seed reproduces the mask, so backward = forward applied to the gradient. */
+int bdv_dropout(const float* x, float* out, int64_t numel, float p, uint64_t seed, void* stream);
+
+/* ---- fused losses -------------------------------------------------------------------------- */
+/* libs/losses/lsc_loss.py:30-58 (exclude_pos_denominator, optional hinge).  Writes loss (1),
+ * dsim (B,K) and deta (1) for upstream gradient 1; callers scale. */
+int bdv_lsc_loss(const float* sim, const int64_t* targets, const float* eta, float margin, int hinge,
+                 float* loss, float* dsim, float* deta, int B, int K, void* stream);
+/* libs/cil/icarl.py:123-125 soft-target CE: loss = mean_b(-sum_k tgt*log_softmax(score)).
+ * `soft_targets` (B,K) or NULL with integer `labels` (B) (= plain mean cross-entropy). */
+int bdv_softce_loss(const float* score, const float* soft_targets, const int64_t* labels, float* loss,
+                    float* dscore, int B, int K, void* stream);
+/* icarl.py:101,113-120: targets = onehot(label); rows with label < prev_K <- softmax(prev_logits) */
+int bdv_icarl_targets(const int64_t* labels, const float* prev_logits, int prev_K, float* targets,
+                      int B, int K, void* stream);
+/* UPSTREAM Recognizer2D average_clip('prob'): (B*n,K) -> softmax over K, mean over n -> (B,K) */
+int bdv_softmax_mean(const float* s, float* out, int B, int n, int K, int apply_softmax, void* stream);
+/* UPSTREAM top_k_accuracy: acc[0]=top-1, acc[1]=top-5 hit rates, computed on device (no D2H sync) */
+int bdv_topk_acc(const float* score, const int64_t* labels, float* acc, int B, int K, void* stream);
+/* libs/cil/cil.py:519-541 feature distillation: mse = mean((cur-prev)^2); dcur = gscale*2*(cur-prev)/numel */
+size_t bdv_reduce_workspace_bytes(void);
+int bdv_kd_mse_fwd(const float* cur, const float* prev, float* mse, int64_t numel, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int bdv_kd_mse_bwd(const float* cur, const float* prev, const float* gscale_dev, float gscale_host,
+                   float* dcur, int64_t numel, void* stream);
+
+/* ---- optimizer: multi-tensor global-norm clip + SGD(momentum, wd) ---------------------------
+ * torch.optim.SGD built at libs/cil/cil.py:467 with the groups of libs/models/cil_heads/tsm.py:273-303
+ * and PL gradient_clip_val (cil.py:743).  Tables are device arrays, one entry per tensor. */
+int bdv_multi_sqnorm(const float* const* grads, const int64_t* numels, int ntensors, float* out_sqnorm,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/* clip_coef (device scalar) = min(1, max_norm / (sqrt(sqnorm)*grad_scale + 1e-6)); max_norm <= 0 -> 1 */
+int bdv_clip_coef(const float* sqnorm, float grad_scale, float max_norm, float* clip_coef, void* stream);
+/* g = grad*grad_scale*clip_coef + wd*p ; buf = momentum*buf + g ; p -= lr*buf */
+int bdv_multi_sgd(float* const* params, const float* const* grads, float* const* bufs,
+                  const int64_t* numels, const float* lrs, const float* wds, int ntensors,
+                  float momentum, float grad_scale, const float* clip_coef, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BDVCIL_HIP_H */

@@ -1,0 +1,138 @@
+"""Parity of the implicit-GEMM conv kernels (fprop / dgrad / wgrad, with the fused temporal shift)
+against the CPU oracle: torch fp32 conv2d + oracle.temporal_shift + autograd, same seeded inputs.
+Tolerance: fp32 arithmetic on both sides, only the summation order differs -> 2e-5 of the output scale."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.tsm_oracle import temporal_shift
+
+pytestmark = pytest.mark.gpu
+
+# (N, H, W, Cin, Cout, R, stride, pad, T, fold)
+CASES = [
+    (8, 14, 14, 64, 128, 1, 1, 0, 1, 0),      # plain 1x1, 128-wide tile
+    (16, 7, 7, 64, 64, 1, 1, 0, 8, 8),        # 1x1 + shift, fold 8 (layer1.0.conv1), 64-wide tile
+    (16, 6, 6, 256, 128, 1, 1, 0, 8, 32),     # 1x1 + shift, ragged M (576 rows)
+    (8, 8, 8, 64, 128, 1, 2, 0, 1, 0),        # 1x1 stride 2 (downsample)
+    (4, 10, 10, 64, 64, 3, 1, 1, 1, 0),       # 3x3
+    (2, 9, 9, 128, 128, 3, 1, 1, 1, 0),       # 3x3, odd size
+    (8, 8, 8, 64, 128, 3, 2, 1, 8, 8),        # 3x3 stride 2 + shift (BasicBlock conv1)
+    (16, 5, 5, 128, 256, 3, 2, 1, 8, 16),     # 3x3 stride 2 + shift, odd size
+    (2, 32, 32, 4, 64, 7, 2, 3, 1, 0),        # stem 7x7 on NHWC4
+    (3, 18, 22, 4, 64, 7, 2, 3, 1, 0),        # stem, non-square, ragged
+]
+
+
+def _ref(x_nchw, w_oihw, stride, pad, T, fold):
+    xs = x_nchw
+    if fold > 0:
+        xs = temporal_shift(x_nchw, T, x_nchw.shape[1] // fold)
+    return F.conv2d(xs, w_oihw, stride=stride, padding=pad)
+
+
+def _mk(case, seed=0):
+    N, H, W, Cin, Cout, R, st, pad, T, fold = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, R, R, generator=g) / (Cin * R * R) ** 0.5
+    if Cin == 4:            # stem: 4th channel is padding
+        x[:, 3] = 0
+    return x, w
+
+
+def _close(a, b, tol=2e-5):
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale + 1e-7, f'max err {err} vs scale {scale}'
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_fprop(case, dev):
+    from bdvcil_amd import kernels as K
+    N, H, W, Cin, Cout, R, st, pad, T, fold = case
+    x, w = _mk(case)
+    ref = _ref(x, w, st, pad, T, fold)
+    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
+    y = K.conv_fprop(x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), g)
+    torch.cuda.synchronize()
+    _close(y.cpu().permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[3] % 64 == 0])
+@pytest.mark.parametrize('with_add', [False, True])
+def test_dgrad(case, with_add, dev):
+    from bdvcil_amd import kernels as K
+    N, H, W, Cin, Cout, R, st, pad, T, fold = case
+    x, w = _mk(case, 1)
+    x.requires_grad_(True)
+    y = _ref(x, w, st, pad, T, fold)
+    gen = torch.Generator().manual_seed(7)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    ref = x.grad
+    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
+    add = mask = None
+    if with_add:
+        add = torch.randn(N, H, W, Cin, generator=gen)
+        mask = torch.randn(N, H, W, Cin, generator=gen)
+        ref = ref + (add * (mask > 0)).permute(0, 3, 1, 2)
+    dx = K.conv_dgrad(dy.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), g,
+                      add_src=None if add is None else add.to(dev), add_mask_src=None if mask is None else mask.to(dev))
+    torch.cuda.synchronize()
+    _close(dx.cpu().permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_wgrad(case, dev):
+    from bdvcil_amd import kernels as K
+    N, H, W, Cin, Cout, R, st, pad, T, fold = case
+    x, w = _mk(case, 2)
+    w.requires_grad_(True)
+    y = _ref(x, w, st, pad, T, fold)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(9))
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1)
+    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    dw = K.conv_wgrad(dyd, xd, g)
+    torch.cuda.synchronize()
+    _close(dw.cpu(), ref)
+    # accumulate (beta = 1) doubles the gradient
+    dw2 = K.conv_wgrad(dyd, xd, g, dw=dw.clone(), beta=1.0)
+    torch.cuda.synchronize()
+    _close(dw2.cpu(), 2 * ref)
+
+
+def test_linearity_full_size(dev):
+    """Size-independent property at a BASELINE-size site (layer3 conv2: 256->256 3x3 on 14x14, N=256):
+    conv(a*x1 + x2) == a*conv(x1) + conv(x2), and the kernel is deterministic run to run."""
+    from bdvcil_amd import kernels as K
+    g = K.make_geom(256, 14, 14, 256, 256, 3, 3, 1, 1)
+    gen = torch.Generator(device='cpu').manual_seed(3)
+    x1 = torch.randn(256, 14, 14, 256, generator=gen).to(dev)
+    x2 = torch.randn(256, 14, 14, 256, generator=gen).to(dev)
+    w = (torch.randn(256, 3, 3, 256, generator=gen) / 48).to(dev)
+    y1, y2 = K.conv_fprop(x1, w, g), K.conv_fprop(x2, w, g)
+    y12 = K.conv_fprop(2.0 * x1 + x2, w, g)
+    y1b = K.conv_fprop(x1, w, g)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y1b)
+    err = (y12 - (2.0 * y1 + y2)).abs().max().item()
+    assert err <= 2e-5 * y12.abs().max().item()
+
+
+def test_bad_shapes_raise(dev):
+    from bdvcil_amd import kernels as K
+    from bdvcil_amd._lib import HipExtensionError
+    g = K.make_geom(2, 8, 8, 64, 64, 3, 3, 1, 1)
+    x = torch.zeros(2, 8, 8, 64, device=dev)
+    w = torch.zeros(64, 3, 3, 64, device=dev)
+    with pytest.raises(ValueError):
+        K.conv_fprop(x[:, :4], w, g)                      # wrong shape
+    with pytest.raises(RuntimeError):
+        K.conv_fprop(x.cpu(), w.cpu(), g)                 # CPU tensors: no fallback
+    bad = K.make_geom(2, 8, 8, 64, 96, 3, 3, 1, 1)        # Cout not a multiple of 64
+    with pytest.raises(HipExtensionError):
+        K.conv_fprop(x, torch.zeros(96, 3, 3, 64, device=dev), bad)
