@@ -2,10 +2,28 @@
 
 Import as ``bdvcil_amd`` (see ``bdvcil_amd.py`` at the repo root).  Layout:
 
-* ``csrc/``      hand-written HIP kernels for gfx950 + the C ABI (``include/bdvcil_hip.h``)
-* ``_lib``       ctypes binding (lazy, per process, no fallback)
-* ``kernels``    tensor-level wrappers (shape checks + launch on torch's current stream)
+* ``csrc/``        hand-written HIP kernels for gfx950 + the C ABI (``include/bdvcil_hip.h``)
+* ``_lib``         ctypes binding (lazy, per process, no fallback)
+* ``kernels``      tensor-level wrappers (shape checks + launch on torch's current stream)
+* ``functional``   autograd glue (block-level Functions)
+* ``registry``, ``recognizer``, ``resnet_tsm``, ``heads``, ``losses``, ``hooks``, ``optim``
+                   the reference's mmaction2-style plugin surface (same names / signatures / state_dict keys)
+* ``frontend``     fused background-mix + normalize
+* ``cil_step``     training-step arithmetic of BaseCIL / ICARLModel + a step engine
+* ``ddp``          bucketed gradient all-reduce over RCCL
 """
 from . import _lib, kernels  # noqa: F401
+from .registry import (BACKBONES, HEADS, LOSSES, OPTIMIZER_BUILDERS, RECOGNIZERS, Registry, build_backbone,  # noqa: F401
+                       build_head, build_loss, build_model)
+from .resnet_tsm import Nhwc4Frames, ResNetTSM, TemporalShift  # noqa: F401
+from .heads import LSC, AvgConsensus, IncrementalNet, IncrementalTSMHead  # noqa: F401
+from .losses import ACMSmoothCE, CrossEntropyLoss, LSCLoss, SoftTargetCrossEntropy  # noqa: F401
+from .recognizer import CILRecognizer2D, Recognizer2D  # noqa: F401
+from .hooks import OutputHook, rgetattr  # noqa: F401
+from .optim import (CILTSMOptimizerConstructor, CILTSMOptimizerConstructorImprovised, FusedSGD, build_lr_scheduler,  # noqa: F401
+                    build_optimizer)
+from .frontend import BackgroundMixFrontEnd  # noqa: F401
+from .cil_step import TrainEngine, base_training_step, icarl_training_step  # noqa: F401
+from .ddp import GradAllReducer, broadcast_parameters  # noqa: F401
 
 __version__ = '0.1.0'

@@ -1,0 +1,331 @@
+"""autograd glue: every differentiable step of the hot path is a ``torch.autograd.Function`` whose
+forward/backward only enqueue kernels of ``libbdvcil_hip.so`` (through ``kernels``).
+
+Granularity is chosen so that no gradient junction inside a residual block is left to autograd
+(the identity-path add and its ReLU mask are fused into the conv1 dgrad epilogue):
+
+* ``StemFn``      NHWC4 frames -> conv7x7/2 + BN + ReLU + maxpool3x3/2
+* ``ResBlockFn``  one BasicBlock / Bottleneck incl. temporal shift, BN, ReLU, residual
+* ``AvgPoolFn``, ``DropoutFn``, ``LSCFn``, ``LinearFn``, ``ConsensusFn``
+* ``LSCLossFn``, ``SoftCEFn``, ``KDMSEFn``
+
+Internal activation layout is NHWC fp32; module boundaries expose NCHW *views* of the same
+storage (``nhwc_to_nchw_view``), so hooks and feature-distillation see mmaction-shaped tensors.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import kernels as K
+
+
+def nhwc_to_nchw_view(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 3, 1, 2)
+
+
+def nchw_view_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    y = x.permute(0, 2, 3, 1)
+    return y if y.is_contiguous() else y.contiguous()
+
+
+def weight_krsc(w: torch.Tensor) -> torch.Tensor:
+    """OIHW parameter (channels_last storage) -> (Cout,R,S,Cin) contiguous view (copy only if the
+    parameter is not channels_last, e.g. a foreign checkpoint tensor assigned by hand)."""
+    v = w.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+class UnitSpec:
+    """Static description of one conv+BN(+ReLU) site inside a block."""
+
+    def __init__(self, cin, cout, k, stride, pad, relu, shift_div=0, num_segments=1):
+        self.cin, self.cout, self.k, self.stride, self.pad, self.relu = cin, cout, k, stride, pad, relu
+        self.fold = cin // shift_div if shift_div else 0
+        self.T = num_segments if shift_div else 1
+
+    def geom(self, N, H, W):
+        return K.make_geom(N, H, W, self.cin, self.cout, self.k, self.k, self.stride, self.pad, self.T, self.fold)
+
+
+def _bn_forward(y, bn, gamma, beta, training):
+    """-> (mean, invstd, scale, shift); running stats are updated in place when training."""
+    if training:
+        if bn.momentum is None:
+            raise NotImplementedError('BatchNorm momentum=None (cumulative average) is not supported by the HIP path')
+        rm = bn.running_mean if bn.track_running_stats else None
+        rv = bn.running_var if bn.track_running_stats else None
+        return K.bn_train_stats(y, gamma, beta, bn.eps, bn.momentum, rm, rv)
+    scale, shift = K.bn_eval_params(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
+    return None, None, scale, shift
+
+
+class StemFn(torch.autograd.Function):
+    """UPSTREAM ResNet.conv1 (7x7/2 ConvModule) + ResNet.maxpool on NHWC4 input."""
+
+    @staticmethod
+    def forward(ctx, x4, weight, gamma, beta, bn, training):
+        N, H, W, _ = x4.shape
+        g = K.make_geom(N, H, W, 4, weight.shape[0], weight.shape[2], weight.shape[3], 2, weight.shape[2] // 2)
+        w4 = torch.zeros((weight.shape[0], weight.shape[2], weight.shape[3], 4), dtype=torch.float32, device=x4.device)
+        w4[..., :3] = weight.detach().permute(0, 2, 3, 1)           # 37 KB repack, plumbing
+        y = K.conv_fprop(x4, w4, g)
+        mean, invstd, scale, shift = _bn_forward(y, bn, gamma, beta, training)
+        a = K.bn_apply(y, scale, shift, None, True)
+        p, idx = K.maxpool_fwd(a)
+        ctx.g = g
+        ctx.bn_training = training
+        if training and any(ctx.needs_input_grad):
+            ctx.save_for_backward(x4, gamma, y, a, idx, mean, invstd)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        if not ctx.bn_training:
+            raise NotImplementedError('backward through eval-mode BatchNorm is not implemented (norm_eval=False in all CIL configs)')
+        x4, gamma, y, a, idx, mean, invstd = ctx.saved_tensors
+        dp = dp if dp.is_contiguous() else dp.contiguous()
+        da = K.maxpool_bwd(dp, idx, tuple(a.shape))
+        dy, dgamma, dbeta = K.bn_backward(da, a, y, gamma, mean, invstd, True)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw4 = K.conv_wgrad(dy, x4, ctx.g)
+            dw = dw4[..., :3].permute(0, 3, 1, 2)
+        return None, dw, dgamma, dbeta, None, None
+
+
+class ResBlockFn(torch.autograd.Function):
+    """One residual block (UPSTREAM BasicBlock / Bottleneck, shift_place='blockres')."""
+
+    @staticmethod
+    def forward(ctx, x, blk, training, *params):
+        units: List[UnitSpec] = blk.unit_specs
+        bns = blk.unit_bns
+        n_main = blk.n_main
+        has_down = len(units) > n_main
+        N, H, W, _ = x.shape
+        save = training and any(ctx.needs_input_grad)
+        saved = [x]
+        geoms = []
+        # identity path
+        if has_down:
+            u = units[n_main]
+            wd, gd, bd = params[3 * n_main:3 * n_main + 3]
+            g = u.geom(N, H, W)
+            yd = K.conv_fprop(x, weight_krsc(wd), g)
+            mean_d, invstd_d, sc, sh = _bn_forward(yd, bns[n_main], gd, bd, training)
+            identity = K.bn_apply(yd, sc, sh, None, False)
+        else:
+            identity = x
+        cur = x
+        h, w_ = H, W
+        for i in range(n_main):
+            u = units[i]
+            wt, gm, bt = params[3 * i:3 * i + 3]
+            g = u.geom(N, h, w_)
+            geoms.append(g)
+            y = K.conv_fprop(cur, weight_krsc(wt), g)
+            mean, invstd, sc, sh = _bn_forward(y, bns[i], gm, bt, training)
+            last = i == n_main - 1
+            a = K.bn_apply(y, sc, sh, identity if last else None, True if last else u.relu)
+            if save:
+                saved += [y, a, mean, invstd]
+            cur = a
+            h, w_ = g.Ho, g.Wo
+        if save:
+            if has_down:
+                saved += [yd, mean_d, invstd_d]
+                geoms.append(units[n_main].geom(N, H, W))
+            ctx.save_for_backward(*saved, *params)
+            ctx.n_saved = len(saved)
+        ctx.geoms = geoms
+        ctx.n_main = n_main
+        ctx.has_down = has_down
+        ctx.bn_training = training
+        return cur
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.bn_training:
+            raise NotImplementedError('backward through eval-mode BatchNorm is not implemented (norm_eval=False in all CIL configs)')
+        t = ctx.saved_tensors
+        saved, params = t[:ctx.n_saved], t[ctx.n_saved:]
+        n_main, has_down = ctx.n_main, ctx.has_down
+        x = saved[0]
+        ys = [saved[1 + 4 * i] for i in range(n_main)]
+        acts = [saved[2 + 4 * i] for i in range(n_main)]
+        means = [saved[3 + 4 * i] for i in range(n_main)]
+        invstds = [saved[4 + 4 * i] for i in range(n_main)]
+        out = acts[-1]
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        need = ctx.needs_input_grad      # (x, blk, training, *params)
+        grads: List[Optional[torch.Tensor]] = [None] * len(params)
+        need_dx = need[0]
+
+        # main branch, last unit first.  ``d`` is the gradient w.r.t. the unit's (post-ReLU) output.
+        d, mask_out = dout, out
+        for i in range(n_main - 1, -1, -1):
+            wt, gm = params[3 * i], params[3 * i + 1]
+            dy, dg, db = K.bn_backward(d, mask_out, ys[i], gm, means[i], invstds[i], True)
+            grads[3 * i + 1], grads[3 * i + 2] = dg, db
+            inp = acts[i - 1] if i > 0 else x
+            if need[3 + 3 * i]:
+                grads[3 * i] = K.conv_wgrad(dy, inp, ctx.geoms[i]).permute(0, 3, 1, 2)
+            if i > 0:
+                d = K.conv_dgrad(dy, weight_krsc(wt), ctx.geoms[i])
+                mask_out = acts[i - 1]
+            else:
+                dy_first = dy
+
+        dx = None
+        if has_down:
+            yd, mean_d, invstd_d = saved[1 + 4 * n_main:4 + 4 * n_main]
+            wd, gd = params[3 * n_main], params[3 * n_main + 1]
+            gdn = ctx.geoms[n_main]
+            # gradient entering the downsample BN is dout * (out > 0): same mask as the block output
+            dyd, dgd, dbd = K.bn_backward(dout, out, yd, gd, mean_d, invstd_d, True)
+            grads[3 * n_main + 1], grads[3 * n_main + 2] = dgd, dbd
+            if need[3 + 3 * n_main]:
+                grads[3 * n_main] = K.conv_wgrad(dyd, x, gdn).permute(0, 3, 1, 2)
+            if need_dx:
+                dx_id = K.conv_dgrad(dyd, weight_krsc(wd), gdn)
+                dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), ctx.geoms[0], add_src=dx_id)
+        elif need_dx:
+            # identity path: dout * (out > 0), fused into the conv1 dgrad epilogue
+            dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), ctx.geoms[0], add_src=dout, add_mask_src=out)
+        return (dx, None, None, *grads)
+
+
+class AvgPoolFn(torch.autograd.Function):
+    """UPSTREAM TSMHead.avg_pool = AdaptiveAvgPool2d(1) on an NCHW view of NHWC storage."""
+
+    @staticmethod
+    def forward(ctx, x_nchw):
+        x = nchw_view_to_nhwc(x_nchw)
+        ctx.in_shape = tuple(x.shape)
+        return K.avgpool_fwd(x).view(x.shape[0], x.shape[3], 1, 1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, H, W, C = ctx.in_shape
+        d = dout.reshape(N, C)
+        d = d if d.is_contiguous() else d.contiguous()
+        return nhwc_to_nchw_view(K.avgpool_bwd(d, ctx.in_shape))
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return K.dropout(x.contiguous(), p, seed)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return K.dropout(dout.contiguous(), ctx.p, ctx.seed), None, None
+
+
+class LSCFn(torch.autograd.Function):
+    """libs/models/cil_heads/cosine_linear.py:27-43."""
+
+    @staticmethod
+    def forward(ctx, x, weights, out_features, nb_proxies):
+        x = x.contiguous()
+        sim, xn, wn, cb = K.lsc_fwd(x, weights, out_features, nb_proxies)
+        ctx.save_for_backward(x, weights, xn, wn, cb)
+        ctx.kp = (out_features, nb_proxies)
+        return sim
+
+    @staticmethod
+    def backward(ctx, dsim):
+        x, w, xn, wn, cb = ctx.saved_tensors
+        Kc, P = ctx.kp
+        dx, dw = K.lsc_bwd(dsim.contiguous(), x, w, xn, wn, cb, Kc, P, need_dw=ctx.needs_input_grad[1])
+        return dx, dw, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """libs/models/cil_heads/inc_net.py:36-37."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return K.linear_fwd(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dx, dw, db = K.linear_bwd(dout.contiguous(), x, w, need_dx=ctx.needs_input_grad[0], need_dw=need_w,
+                                  need_db=ctx.has_bias)
+        return dx, dw, (db if ctx.has_bias else None)
+
+
+class ConsensusFn(torch.autograd.Function):
+    """UPSTREAM AvgConsensus(dim=1): (B,T,K) -> (B,1,K)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, T, Kc = x.shape
+        ctx.T = T
+        return K.consensus_fwd(x.reshape(B * T, Kc).contiguous(), B, T).view(B, 1, Kc)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, _, Kc = dout.shape
+        return K.consensus_bwd(dout.reshape(B, Kc).contiguous(), ctx.T).view(B, ctx.T, Kc)
+
+
+def _scale_by(grad_out: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """Upstream scalar gradient times a small saved tensor ((B,K) or (1,)); host-free."""
+    return t * grad_out
+
+
+class LSCLossFn(torch.autograd.Function):
+    """libs/losses/lsc_loss.py:36-56; forward kernel also produces dsim and deta."""
+
+    @staticmethod
+    def forward(ctx, sim, targets, eta, margin, hinge):
+        loss, dsim, deta = K.lsc_loss(sim.contiguous(), targets.contiguous(), eta, margin, hinge)
+        ctx.save_for_backward(dsim, deta)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dsim, deta = ctx.saved_tensors
+        return _scale_by(g, dsim), None, (_scale_by(g, deta) if ctx.needs_input_grad[2] else None), None, None
+
+
+class SoftCEFn(torch.autograd.Function):
+    """libs/cil/icarl.py:123-125 (soft targets) or plain mean cross-entropy (integer labels)."""
+
+    @staticmethod
+    def forward(ctx, score, soft_targets, labels):
+        loss, dscore = K.softce_loss(score.contiguous(), soft_targets, labels)
+        ctx.save_for_backward(dscore)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dscore,) = ctx.saved_tensors
+        return _scale_by(g, dscore), None, None
+
+
+class KDMSEFn(torch.autograd.Function):
+    """nn.MSELoss() between hooked feature maps (libs/cil/cil.py:519-541); ``prev`` gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, cur, prev):
+        ctx.save_for_backward(cur, prev)
+        return K.kd_mse_fwd(cur, prev)
+
+    @staticmethod
+    def backward(ctx, g):
+        cur, prev = ctx.saved_tensors
+        return K.kd_mse_bwd(cur, prev, g.reshape(1).contiguous(), 1.0), None
+
+
+def kd_mse(cur: torch.Tensor, prev: torch.Tensor) -> torch.Tensor:
+    return KDMSEFn.apply(cur, prev.detach())

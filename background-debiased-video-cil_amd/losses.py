@@ -1,0 +1,78 @@
+"""``libs.losses`` API on the HIP kernels: same class names, constructor arguments and call signatures
+as libs/losses/lsc_loss.py and libs/losses/acm_smooth_ce.py, registered in ``LOSSES``."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from . import kernels as K
+from .registry import LOSSES
+
+
+@LOSSES.register_module()
+class LSCLoss(nn.Module):
+    """libs/losses/lsc_loss.py:8-58.  ``forward(similarities (B,K), targets (B,), **kwargs) -> scalar``."""
+
+    def __init__(self, eta=1.0, margin=0.6, learnable_eta=True, exclude_pos_denominator=True, hinge_proxynca=True,
+                 class_weights=None):
+        super().__init__()
+        self.margin = margin
+        self.exclude_pos_denominator = exclude_pos_denominator
+        self.hinge_proxynca = hinge_proxynca
+        self.class_weights = class_weights
+        self.learnable_eta = learnable_eta
+        self.eta = nn.Parameter(torch.Tensor([eta]), requires_grad=self.learnable_eta)
+
+    def forward(self, similarities: torch.Tensor, targets: torch.Tensor, **kwargs):
+        if self.class_weights is not None:
+            raise NotImplementedError('class_weights is None in every shipped config (SURVEY.md section 8); not on the HIP path')
+        if targets.dim() == 0:
+            targets = targets.unsqueeze(0)
+        if self.exclude_pos_denominator:
+            return Fn.LSCLossFn.apply(similarities, targets, self.eta, float(self.margin), bool(self.hinge_proxynca))
+        return Fn.SoftCEFn.apply(similarities, None, targets.contiguous())      # lsc_loss.py:58: plain cross entropy
+
+
+@LOSSES.register_module()
+class CrossEntropyLoss(nn.Module):
+    """Mean cross-entropy on integer labels (BASELINE config 2 "CE loss only").  Unlike UPSTREAM mmaction
+    CrossEntropyLoss it tolerates the ``batch_data`` / ``num_classes`` kwargs CILRecognizer2D adds
+    (SURVEY Appendix A notes the upstream one would raise on them)."""
+
+    def __init__(self, loss_weight=1.0, class_weight=None):
+        super().__init__()
+        if class_weight is not None:
+            raise NotImplementedError('class_weight is not on the HIP path')
+        self.loss_weight = loss_weight
+
+    def forward(self, cls_score, label, **kwargs):
+        if label.dim() == 0:
+            label = label.unsqueeze(0)
+        loss = Fn.SoftCEFn.apply(cls_score, None, label.contiguous())
+        return loss if self.loss_weight == 1.0 else loss * self.loss_weight
+
+
+@LOSSES.register_module()
+class SoftTargetCrossEntropy(nn.Module):
+    """Loss of ``ICARLModel.training_step`` (libs/cil/icarl.py:101-125): one-hot targets whose old-class
+    rows are replaced by softmax(prev-model logits); ``mean_b(-sum_k tgt * log_softmax(score))``."""
+
+    def forward(self, cls_score, labels, prev_logits=None, prev_num_classes=0, **kwargs):
+        tgt = K.icarl_targets(labels.reshape(-1).contiguous(), None if prev_logits is None else prev_logits.contiguous(),
+                              prev_num_classes, cls_score.shape[1])
+        return Fn.SoftCEFn.apply(cls_score, tgt, None)
+
+
+@LOSSES.register_module()
+class ACMSmoothCE(nn.Module):
+    """API name kept for config compatibility (libs/losses/acm_smooth_ce.py:8-30).  Unreachable in every
+    shipped config (all ACM configs use methods='icarl', which bypasses head.loss -- SURVEY section 2 #8),
+    so it is out of scope for the HIP path."""
+
+    def __init__(self, alpha: float = 4):
+        super().__init__()
+        self.alpha = alpha
+
+    def forward(self, cls_score, labels, batch_data, num_classes, **kwargs):
+        raise NotImplementedError('ACMSmoothCE is out of the hot-path scope (never invoked by the reference configs)')

@@ -19,6 +19,8 @@ CASES = [
     (2, 9, 9, 128, 128, 3, 1, 1, 1, 0),       # 3x3, odd size
     (8, 8, 8, 64, 128, 3, 2, 1, 8, 8),        # 3x3 stride 2 + shift (BasicBlock conv1)
     (16, 5, 5, 128, 256, 3, 2, 1, 8, 16),     # 3x3 stride 2 + shift, odd size
+    (32, 7, 7, 512, 512, 3, 1, 1, 8, 64),     # R18 layer4.1.conv1 at B=4 (4 ci-blocks per tap in wgrad)
+    (8, 7, 7, 256, 512, 3, 1, 1, 1, 0),       # several ci-blocks per tap, no shift
     (2, 32, 32, 4, 64, 7, 2, 3, 1, 0),        # stem 7x7 on NHWC4
     (3, 18, 22, 4, 64, 7, 2, 3, 1, 0),        # stem, non-square, ragged
 ]
