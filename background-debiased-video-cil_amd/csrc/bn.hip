@@ -69,18 +69,41 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int RB, int64_t M, int C,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale,
-                                   float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int r = 0; r < RB; ++r) {
-    s += (double)psum[(int64_t)r * C + c];
-    q += (double)psq[(int64_t)r * C + c];
+// Fixed-order column sum of a [RB][C] fp32 slab in fp64: 16 channels x 16 row-lanes per block.
+__device__ __forceinline__ void slab_colsum2(const float* __restrict__ a, const float* __restrict__ b, int RB, int C, int c,
+                                             int rl, double (*sh)[16][17], double& sa, double& sb) {
+  double x = 0.0, y = 0.0;
+  if (c < C) {
+    for (int r = rl; r < RB; r += 16) {
+      x += (double)a[(int64_t)r * C + c];
+      y += (double)b[(int64_t)r * C + c];
+    }
   }
+  const int cl = threadIdx.x & 15;
+  sh[0][rl][cl] = x;
+  sh[1][rl][cl] = y;
+  __syncthreads();
+  sa = 0.0;
+  sb = 0.0;
+  if (rl == 0) {
+    for (int k = 0; k < 16; ++k) {
+      sa += sh[0][k][cl];
+      sb += sh[1][k][cl];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int RB,
+                                                           int64_t M, int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                           float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double sh[2][16][17];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
+  double s, q;
+  slab_colsum2(psum, psq, RB, C, c, rl, sh, s, q);
+  if (rl != 0 || c >= C) return;
   const double mean = s / (double)M;
   double var = q / (double)M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -184,17 +207,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 
 // coef[0][c] = gamma*invstd, coef[1][c] = sum(g)/M, coef[2][c] = sum(g*xhat)/M
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int RB, int64_t M, int C,
-                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float beta_acc,
-                                       float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < RB; ++r) {
-    s1 += (double)p1[(int64_t)r * C + c];
-    s2 += (double)p2[(int64_t)r * C + c];
-  }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int RB,
+                                                               int64_t M, int C, const float* __restrict__ gamma,
+                                                               const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float beta_acc, float* __restrict__ coef) {
+  __shared__ double sh[2][16][17];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
+  double s1, s2;
+  slab_colsum2(p1, p2, RB, C, c, rl, sh, s1, s2);
+  if (rl != 0 || c >= C) return;
   if (dgamma != nullptr) dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)s2;
   if (dbeta != nullptr) dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)s1;
   coef[c] = gamma[c] * invstd[c];
@@ -289,7 +310,7 @@ extern "C" int bdv_bn_train_stats(const float* y, int64_t M, int C, const float*
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_partial_kernel, dim3(b.RB, b.CC), dim3(256), 0, s, y, psum, psq, M, C, b.CVB, b.RL, b.rows_per_block);
   BDV_LAUNCH_CHECK("bdv_bn_train_stats(partial)");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)psum, (const float*)psq, b.RB,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)psum, (const float*)psq, b.RB,
                      M, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
   BDV_LAUNCH_CHECK("bdv_bn_train_stats(finalize)");
   return BDV_OK;
@@ -349,7 +370,7 @@ extern "C" int bdv_bn_backward(const float* dout, const float* out, const float*
     hipLaunchKernelGGL((bn_bwd_partial_kernel<false>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, out, y, save_mean, save_invstd,
                        p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
   BDV_LAUNCH_CHECK("bdv_bn_backward(partial)");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)p1, (const float*)p2, b.RB,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)p1, (const float*)p2, b.RB,
                      M, C, gamma, save_invstd, dgamma, dbeta, beta_acc, coef);
   BDV_LAUNCH_CHECK("bdv_bn_backward(finalize)");
   const int64_t n4 = M * C / 4;

@@ -190,18 +190,31 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const float* __restrict
 
 // =========================================================================================
 // dgrad: dxs[m=(n,h,w), ci] = sum_{tap, co} dy[n, (h+p-r)/st, (w+p-s)/st, co] * w[co, tap, ci]
+// Stride 2 is decomposed into the 4 input-pixel parity classes (blockIdx.y): a class only visits the
+// taps whose (h+p-r) is even, so no MFMA work is spent on structural zeros.
 // epilogue: temporal un-shift (scatter to frame t+/-1) + optional masked residual-gradient add.
 // =========================================================================================
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                           float* __restrict__ dx, const float* __restrict__ add_src,
-                                                          const float* __restrict__ add_mask, Geom g, int MT, int NT) {
+                                                          const float* __restrict__ add_mask, Geom g, int NT) {
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 64, BP = BN / 64;
   constexpr int BV = BN / 4;
   constexpr int STAGE = BK * (LDA + LDB);
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  // parity class of the input pixel (stride 1: a single class)
+  const int st = g.stride;
+  const int ph = blockIdx.y / st, pw = blockIdx.y - ph * st;
+  const int Hc = (g.H - ph + st - 1) / st, Wc = (g.W - pw + st - 1) / st;
+  const int Mc = g.N * Hc * Wc;
+  const int MT = (Mc + BM - 1) / BM;
+  const int r0 = (ph + g.pad) % st, s0 = (pw + g.pad) % st;
+  const int nr = r0 < g.R ? (g.R - r0 + st - 1) / st : 0;
+  const int ns = s0 < g.S ? (g.S - s0 + st - 1) / st : 0;
+  const int bh = (ph + g.pad - r0) / st, bw = (pw + g.pad - s0) / st;
 
   const int id = blockIdx.x;
   const int xcd = id & 7, jj = id >> 3;
@@ -212,6 +225,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict
   const int lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
   const int arow = tid >> 2, kg = tid & 3;
+  const int HcWc = Hc * Wc;
   const int HW = g.H * g.W;
   const int RS = g.R * g.S;
 
@@ -220,33 +234,28 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
     const int m = mt * BM + arow + 64 * p;
-    a_ok[p] = m < g.M;
+    a_ok[p] = m < Mc;
     const int mm = a_ok[p] ? m : 0;
-    const int n = mm / HW;
-    const int rem = mm - n * HW;
-    const int h = rem / g.W;
+    const int n = mm / HcWc;
+    const int rem = mm - n * HcWc;
+    const int hc = rem / Wc;
     a_n[p] = n;
-    a_h[p] = h + g.pad;
-    a_w[p] = rem - h * g.W + g.pad;
+    a_h[p] = hc + bh;
+    a_w[p] = rem - hc * Wc + bw;
   }
 
   float4 ra[AP], rb[BP];
   auto load = [&](int kt) {
     const int k0 = kt * BK;
-    const int tap = k0 / g.Cout;
-    const int co0 = k0 - tap * g.Cout;
-    const int r = tap / g.S, s = tap - r * g.S;
+    const int ct = k0 / g.Cout;             // tap index inside this class
+    const int co0 = k0 - ct * g.Cout;
+    const int ir = ct / ns, is = ct - ir * ns;
+    const int tap = (r0 + ir * st) * g.S + (s0 + is * st);
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      int hn = a_h[p] - r, wn = a_w[p] - s;
-      bool v = a_ok[p] && hn >= 0 && wn >= 0;
-      if (g.stride == 2) {
-        v = v && ((hn | wn) & 1) == 0;
-        hn >>= 1;
-        wn >>= 1;
-      }
-      v = v && hn < g.Ho && wn < g.Wo;
-      const size_t off = ((size_t)(a_n[p] * g.Ho + hn) * g.Wo + wn) * g.Cout + co0 + 4 * kg;
+      const int ho = a_h[p] - ir, wo = a_w[p] - is;
+      const bool v = a_ok[p] && (unsigned)ho < (unsigned)g.Ho && (unsigned)wo < (unsigned)g.Wo;
+      const size_t off = ((size_t)(a_n[p] * g.Ho + ho) * g.Wo + wo) * g.Cout + co0 + 4 * kg;
       ra[p] = v ? *reinterpret_cast<const float4*>(dy + off) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -272,17 +281,19 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = g.Ktot / BK;
-  load(0);
-  store(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load(kt + 1);
-    const float* As = smem + cur * STAGE;
-    mma_stage<LDA, LDB, TM, TN>(As, As + BK * LDA, acc, wm0, wn0, lane);
-    if (kt + 1 < nk) store(cur ^ 1);
+  const int nk = nr * ns * g.Cout / BK;     // 0 for a class no filter tap reaches (e.g. 1x1 stride 2, odd pixels)
+  if (nk > 0) {
+    load(0);
+    store(0);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) load(kt + 1);
+      const float* As = smem + cur * STAGE;
+      mma_stage<LDA, LDB, TM, TN>(As, As + BK * LDA, acc, wm0, wn0, lane);
+      if (kt + 1 < nk) store(cur ^ 1);
+      __syncthreads();
+    }
   }
 
   // Epilogue.  Forward read xs[frame n] = x[frame n + cls]; so the gradient of row m goes to
@@ -290,19 +301,29 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict
   // ("orphans") instead write the zero that the unreachable frame at the other clip end needs,
   // which makes the scatter a bijection over dx.
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = nt * BN + wn0 + 32 * j + (lane & 31);
-    const int cls = shift_class(col, g.fold);
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int e = 0; e < 16; ++e) {
+      const int mrow = mt * BM + wm0 + 32 * i + acc_row(e, lane);
+      if (mrow >= Mc) continue;
+      int row, n;
+      if (st == 1) {
+        row = mrow;
+        n = 0;
+      } else {
+        n = mrow / HcWc;
+        const int rem = mrow - n * HcWc;
+        const int hc = rem / Wc;
+        row = (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
+      }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
-        if (row >= g.M) continue;
+      for (int j = 0; j < TN; ++j) {
+        const int col = nt * BN + wn0 + 32 * j + (lane & 31);
+        const int cls = shift_class(col, g.fold);
         float v = acc[i][j][e];
         int drow = row;
         if (cls != 0) {
-          const int n = row / HW;
+          if (st == 1) n = row / HW;
           const int t = n % g.T;
           if ((unsigned)(t + cls) < (unsigned)g.T) {
             drow = row + cls * HW;
@@ -319,7 +340,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict
         }
         dx[o] = v;
       }
-  }
+    }
 }
 
 // =========================================================================================
@@ -574,18 +595,18 @@ extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const 
   g.M = g.N * g.H * g.W;
   g.Ktot = g.R * g.S * g.Cout;
   hipStream_t s = (hipStream_t)stream;
+  const int st = g.stride;
+  const int Mc0 = g.N * ((g.H + st - 1) / st) * ((g.W + st - 1) / st);   // largest parity class
   if (g.Cin % 128 == 0) {
     constexpr int BM = 128, BN = 128;
-    const int MT = (g.M + BM - 1) / BM, NT = g.Cin / BN;
-    const int grid = ((MT + 7) / 8) * 8 * NT;
-    hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, 2, 2>), dim3(grid), dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g,
-                       MT, NT);
+    const int MT = (Mc0 + BM - 1) / BM, NT = g.Cin / BN;
+    const dim3 grid(((MT + 7) / 8) * 8 * NT, st * st);
+    hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, NT);
   } else {
     constexpr int BM = 256, BN = 64;
-    const int MT = (g.M + BM - 1) / BM, NT = g.Cin / BN;
-    const int grid = ((MT + 7) / 8) * 8 * NT;
-    hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, 4, 1>), dim3(grid), dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g,
-                       MT, NT);
+    const int MT = (Mc0 + BM - 1) / BM, NT = g.Cin / BN;
+    const dim3 grid(((MT + 7) / 8) * 8 * NT, st * st);
+    hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, 4, 1>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, NT);
   }
   BDV_LAUNCH_CHECK("bdv_conv_dgrad");
   return BDV_OK;

@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""Headline benchmark: clips/s, forward + backward + fused SGD step, TSM-ResNet50, 8x3x224x224 clips,
+batch 32 per GPU, fp32 (BASELINE.json configs[1]; synthetic clips, random-init weights).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+``roofline`` (dominant kernel = the fp32-MFMA implicit-GEMM conv; algorithmic FLOP / HIP-event time measured
+inside the timed region) and ``cpu_baseline`` (the CPU oracle timed on this box's host cores, N=1 only).
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+R50_FLOP_PER_CLIP = 194.29e9       # BASELINE.md section 2 (fwd+bwd, conv MACs only, stem dgrad excluded)
+PEAK_F32_MFMA = 157.3e12           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+
+
+def model_cfg(depth, num_classes, head, loss, dropout):
+    in_ch = 2048 if depth == 50 else 512
+    inc = dict(type=head, out_features=num_classes)
+    if head == 'LocalSimilarityClassifier':
+        inc['nb_proxies'] = 1
+    return dict(type='CILRecognizer2D',
+                backbone=dict(type='ResNetTSM', pretrained=None, depth=depth, norm_eval=False, num_segments=8, shift_div=8),
+                cls_head=dict(type='IncrementalTSMHead', num_classes=num_classes, in_channels=in_ch, inc_head_config=inc,
+                              num_segments=8, loss_cls=dict(type=loss), spatial_type='avg',
+                              consensus=dict(type='AvgConsensus', dim=1), dropout_ratio=dropout, init_std=0.001, is_shift=True),
+                train_cfg=None, test_cfg=dict(average_clips='prob'))
+
+
+class ConvTimer:
+    """HIP-event timing of every conv launch on the stream it is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []      # (tag, flops, start_event, end_event)
+        self.enabled = False
+
+    def wrap(self, K):
+        timer = self
+
+        def kernel_tag(kind, g):
+            if kind == 'fprop':
+                return 'conv_fprop_kernel<128,128,2,2>' if g.Cout % 128 == 0 else 'conv_fprop_kernel<256,64,4,1>'
+            if kind == 'dgrad':
+                return 'conv_dgrad_kernel<128,128,2,2>' if g.Cin % 128 == 0 else 'conv_dgrad_kernel<256,64,4,1>'
+            small = (g.Cin % 16 != 0) or (g.Cout % 128 != 0) or (g.Cin % 128 != 0)
+            return 'conv_wgrad_kernel<64,64,2,2>' if small else 'conv_wgrad_kernel<128,128,2,2>'
+
+        def make(kind, fn, geom_pos):
+            def timed(*a, **kw):
+                if not timer.enabled:
+                    return fn(*a, **kw)
+                g = a[geom_pos]
+                cin = 3 if g.Cin == 4 else g.Cin
+                flops = 2.0 * g.N * g.Ho * g.Wo * g.Cout * g.R * g.S * cin
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = fn(*a, **kw)
+                e1.record()
+                timer.records.append((kernel_tag(kind, g), flops, e0, e1))
+                return out
+            return timed
+
+        K.conv_fprop = make('fprop', K.conv_fprop, 2)
+        K.conv_dgrad = make('dgrad', K.conv_dgrad, 2)
+        K.conv_wgrad = make('wgrad', K.conv_wgrad, 2)
+
+    def summary(self):
+        by = {}
+        for tag, flops, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            d = by.setdefault(tag, dict(launches=0, ms=0.0, flops=0.0))
+            d['launches'] += 1
+            d['ms'] += ms
+            d['flops'] += flops
+        return by
+
+
+def cpu_baseline(depth, num_classes, head, loss, budget_s=25.0):
+    """The CPU oracle (pure-torch restatement of the reference path; the reference's own trainer needs mmaction2 /
+    Lightning, which do not exist here) timed on the host cores: fwd + bwd + SGD step, fp32, bounded sample."""
+    from oracle import tsm_oracle as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))     # a 1-GPU box owns a 16-CPU share of the host
+    torch.manual_seed(0)
+    cfg = O.r50_cfg(num_classes=num_classes, depth=depth, head=head, loss=loss, dropout_ratio=0.5)
+    model = O.build_model(cfg)
+    model.train()
+    opt = O.build_sgd(model)
+    B = 2
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.randn(B, 8, 3, 224, 224, generator=g)
+    labels = torch.randint(0, num_classes, (B, 1), generator=g)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        model(imgs, labels)['loss_cls'].backward()
+        opt.step()
+
+    step()                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < budget_s and n < 12):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=round(B * n / dt, 3), unit='clips/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'TSM-R{depth} fwd+bwd+SGD, batch {B} x 8x3x224x224, {n} steps in {dt:.1f}s on {os.cpu_count()} host CPUs '
+                       f'(torch {torch.__version__} CPU, fp32)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--depth', type=int, default=50)
+    ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
+    ap.add_argument('--classes', type=int, default=101)
+    ap.add_argument('--head', default='SimpleLinear', choices=['SimpleLinear', 'LocalSimilarityClassifier'])
+    ap.add_argument('--loss', default='CrossEntropyLoss', choices=['CrossEntropyLoss', 'LSCLoss'])
+    ap.add_argument('--dropout', type=float, default=0.5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import bdvcil_amd as bd
+    from bdvcil_amd import kernels as K
+
+    timer = ConvTimer()
+    if not args.no_kernel_timing:
+        timer.wrap(K)
+
+    torch.manual_seed(0)
+    model = bd.build_model(model_cfg(args.depth, args.classes, args.head, args.loss, args.dropout)).to(dev)
+    model.train()
+    reducer = None
+    if world > 1:
+        bd.broadcast_parameters(model)
+        reducer = bd.GradAllReducer(model, bucket_cap_mb=25.0)
+    opt = bd.build_optimizer(model, dict(type='SGD', constructor='CILTSMOptimizerConstructorImprovised',
+                                         paramwise_cfg=dict(fc_lr_scale_factor=5.0), lr=0.01, momentum=0.9, weight_decay=1e-4))
+    engine = bd.TrainEngine(model, opt, grad_clip=None, reducer=reducer)
+
+    g = torch.Generator().manual_seed(1000 + rank)
+    imgs = torch.randn(args.batch, 8, 3, 224, 224, generator=g).to(dev)
+    labels = torch.randint(0, args.classes, (args.batch, 1), generator=g).to(dev)
+    batch = dict(imgs=imgs, label=labels)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        engine.step(batch)
+    sync()
+    timer.enabled = not args.no_kernel_timing
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = engine.step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    loss_val = float(out['loss_cls'].item())
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        clips = args.batch * world * args.steps
+        value = clips / dt
+        flop_per_clip = R50_FLOP_PER_CLIP if args.depth == 50 else None
+        res = {
+            'metric': 'clips/sec fwd+bwd TSM-R50 8x224^2 bs32/GPU' if args.depth == 50 else f'clips/sec fwd+bwd TSM-R{args.depth}',
+            'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1000.0 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'TSM-ResNet{args.depth} fwd+bwd+SGD step, synthetic {args.batch}x8x3x224x224 clips per GPU, '
+                                   f'{args.classes} classes, {args.head}+{args.loss}, dropout {args.dropout}, random-init weights',
+                       'clips_per_gpu': args.batch, 'global_batch': args.batch * world, 'parallelism': f'dp{world}',
+                       'final_loss': round(loss_val, 5)},
+        }
+        if flop_per_clip:
+            res['config']['model_flop_per_clip'] = flop_per_clip
+            res['config']['step_frac_of_f32_mfma_peak'] = round(value / world * flop_per_clip / PEAK_F32_MFMA, 4)
+        if not args.no_kernel_timing and timer.records:
+            by = timer.summary()
+            dom = max(by, key=lambda k: by[k]['ms'])
+            d = by[dom]
+            achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            tot_ms = sum(v['ms'] for v in by.values())
+            tot_fl = sum(v['flops'] for v in by.values())
+            res['roofline'] = {
+                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(PEAK_F32_MFMA / 1e12, 1), 'unit': 'TFLOP/s',
+                'frac': round(achieved * 1e12 / PEAK_F32_MFMA, 4), 'traffic': None,
+                'kernel': dom, 'launches_per_step': d['launches'] // args.steps,
+                'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+                'algorithmic_gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 2),
+                'all_conv_kernels': {k: {'launches_per_step': v['launches'] // args.steps, 'ms_per_step': round(v['ms'] / args.steps, 3),
+                                         'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in sorted(by.items())},
+                'conv_ms_per_step': round(tot_ms / args.steps, 3), 'conv_tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args.depth, args.classes, args.head, args.loss)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
