@@ -1,0 +1,85 @@
+"""World-size-2 test of the bucketed gradient reducer on CPU (gloo): after finish(), every rank's p.grad holds
+the SUM over ranks and, scaled by grad_scale = 1/world, equals the gradient of the mean loss over the global
+batch (what DDP computes for the reference under ddp_spawn, libs/cil/cil.py:704-709)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _toy():
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Conv2d(3, 8, 3, bias=False), nn.BatchNorm2d(8), nn.ReLU(), nn.Flatten(), nn.Linear(8 * 36, 5))
+
+
+def _worker(rank, world, port, bucket_mb, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bdvcil_amd as bd
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = _toy()
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)                      # rank 1 starts different: broadcast must fix it
+    bd.broadcast_parameters(model)
+    model[0].weight.data = model[0].weight.data.contiguous(memory_format=torch.channels_last)
+    reducer = bd.GradAllReducer(model, bucket_cap_mb=bucket_mb)
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(4, 3, 8, 8, generator=g)
+    y = torch.randint(0, 5, (4,), generator=g)
+    xs, ys = x[rank * 2:(rank + 1) * 2], y[rank * 2:(rank + 1) * 2]
+    out = {}
+    for step in range(2):                        # two steps: buckets are reusable
+        for p in model.parameters():
+            p.grad = None
+        nn.functional.cross_entropy(model(xs), ys).backward()
+        reducer.finish()
+        out[step] = [(p.grad * reducer.grad_scale).clone() for p in model.parameters()]
+    q.put((rank, [t.numpy() for t in out[1]], len(reducer.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('bucket_mb', [25.0, 0.001])
+def test_gloo_world2_allreduce_matches_full_batch(bucket_mb):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_mb, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    # both ranks hold identical averaged gradients
+    for a, b in zip(res[0][1], res[1][1]):
+        assert (abs(a - b)).max() == 0
+    if bucket_mb < 1:
+        assert res[0][2] > 1                     # several buckets exercised
+    # BN uses per-rank statistics (no SyncBN in the reference), so compare against the mean of per-rank losses
+    model = _toy()
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(4, 3, 8, 8, generator=g)
+    y = torch.randint(0, 5, (4,), generator=g)
+    loss = 0.5 * (nn.functional.cross_entropy(model(x[:2]), y[:2]) + nn.functional.cross_entropy(model(x[2:]), y[2:]))
+    loss.backward()
+    for got, p in zip(res[0][1], model.parameters()):
+        assert torch.allclose(torch.from_numpy(got), p.grad, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,138 @@
+"""CPU tests of the oracle itself: pinned against the golden vectors generated from the reference's own
+cosine_linear.py / inc_net.py / lsc_loss.py (tests/golden/make_golden.py), plus definition-level checks of the
+UPSTREAM restatements (temporal shift by slicing, param-group census of SURVEY section 8(c)(6))."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tsm_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'head_loss_golden.npz')
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_lsc_and_lscloss_match_reference_golden():
+    gz = np.load(GOLD)
+    assert int(gz['n_lsc']) == 5
+    for i in range(int(gz['n_lsc'])):
+        p = f'lsc{i}_'
+        x = _t(gz[p + 'x']).requires_grad_(True)
+        w = _t(gz[p + 'w']).requires_grad_(True)
+        eta = _t(gz[p + 'eta']).requires_grad_(True)
+        y = _t(gz[p + 'y'])
+        K, P = w.shape[0], int(gz[p + 'P'])
+        sim = O.lsc_forward(x, w, K, P)
+        sim.retain_grad()
+        loss = O.lsc_loss(sim, y, eta)
+        loss.backward()
+        assert torch.allclose(sim, _t(gz[p + 'sim']), rtol=0, atol=1e-6)
+        assert torch.allclose(loss, _t(gz[p + 'loss']), rtol=1e-6, atol=1e-7)
+        assert torch.allclose(sim.grad, _t(gz[p + 'dsim']), rtol=1e-5, atol=1e-8)
+        assert torch.allclose(x.grad, _t(gz[p + 'dx']), rtol=1e-4, atol=1e-8)
+        assert torch.allclose(w.grad, _t(gz[p + 'dw']), rtol=1e-4, atol=1e-8)
+        assert torch.allclose(eta.grad, _t(gz[p + 'deta']), rtol=1e-5, atol=1e-7)
+        assert bool(gz[p + 'grown_old_rows_kept']) and tuple(gz[p + 'grown_shape']) == (K + 5, w.shape[1])
+
+
+def test_lscloss_hinge_corner_matches_reference_golden():
+    gz = np.load(GOLD)
+    sim = _t(gz['hinge_sim']).requires_grad_(True)
+    eta = torch.tensor([10.0], requires_grad=True)
+    loss = O.lsc_loss(sim, _t(gz['hinge_y']), eta)
+    loss.backward()
+    assert torch.allclose(loss, _t(gz['hinge_loss']), rtol=1e-6)
+    assert torch.allclose(sim.grad, _t(gz['hinge_dsim']), rtol=1e-5, atol=1e-8)
+    assert torch.allclose(eta.grad, _t(gz['hinge_deta']), rtol=1e-5, atol=1e-8)
+
+
+def test_incremental_net_matches_reference_golden():
+    gz = np.load(GOLD)
+    for i in range(int(gz['n_inc'])):
+        p = f'inc{i}_'
+        net = O.IncrementalNet(gz[p + 'x'].shape[1], gz[p + 'w'].shape[0])
+        with torch.no_grad():
+            net.weight.copy_(_t(gz[p + 'w']))
+            net.bias.copy_(_t(gz[p + 'b']))
+        x = _t(gz[p + 'x']).requires_grad_(True)
+        out = net(x)
+        out.backward(_t(gz[p + 'dy']))
+        assert torch.allclose(out, _t(gz[p + 'out']), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(x.grad, _t(gz[p + 'dx']), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(net.weight.grad, _t(gz[p + 'dw']), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(net.bias.grad, _t(gz[p + 'db']), rtol=1e-5, atol=1e-6)
+        K = net.out_features
+        net.update_fc(K + 3)
+        assert torch.equal(net.weight.detach()[:K], _t(gz[p + 'w'])) and bool(gz[p + 'grown_old_rows_kept'])
+        assert torch.equal(net.bias.detach(), _t(gz[p + 'grown_b']))
+
+
+def test_temporal_shift_by_slicing_definition():
+    """SURVEY section 8(c) golden (1): x (2*8, 16, 3, 3) arange, expected by the slicing definition."""
+    T, C = 8, 16
+    x = torch.arange(2 * T * C * 9, dtype=torch.float32).view(2 * T, C, 3, 3)
+    out = O.temporal_shift(x, T, 8)
+    v, o = x.view(2, T, C, 9), out.view(2, T, C, 9)
+    fold = C // 8
+    assert torch.equal(o[:, :-1, :fold], v[:, 1:, :fold]) and o[:, -1, :fold].abs().sum() == 0
+    assert torch.equal(o[:, 1:, fold:2 * fold], v[:, :-1, fold:2 * fold]) and o[:, 0, fold:2 * fold].abs().sum() == 0
+    assert torch.equal(o[:, :, 2 * fold:], v[:, :, 2 * fold:])
+    # the shift never crosses a clip boundary
+    x2 = x.clone()
+    x2[T:] += 1000.0
+    assert torch.equal(O.temporal_shift(x2, T, 8)[:T], out[:T])
+
+
+@pytest.mark.parametrize('depth,n_conv,n_bn_tensors,n_blocks', [(18, 20, 40, 8), (34, 36, 72, 16), (50, 53, 106, 16)])
+def test_param_group_census(depth, n_conv, n_bn_tensors, n_blocks):
+    """SURVEY section 8(c) golden (6) / Appendix B: conv counts, BN tensors, shift sites, group hyper-parameters."""
+    m = O.build_model(O.r50_cfg(num_classes=7, depth=depth, head='LocalSimilarityClassifier', loss='LSCLoss'))
+    groups = O.param_groups(m, 0.01, 1e-4, 5.0)
+    assert [len(g['params']) for g in groups] == [1, 0, n_conv - 1, 0, n_bn_tensors, 2, 0]
+    assert [g['lr'] for g in groups] == [0.01, 0.02, 0.01, 0.02, 0.01, 0.05, 0.1]
+    assert [g['weight_decay'] for g in groups] == [1e-4, 0, 1e-4, 0, 0, 1e-4, 0]
+    assert sum(isinstance(x, O.TemporalShift) for x in m.modules()) == n_blocks
+    keys = list(m.state_dict().keys())
+    assert 'backbone.conv1.conv.weight' in keys and 'backbone.layer1.0.conv1.conv.net.weight' in keys
+    assert 'cls_head.fc_cls.weights' in keys and 'cls_head.loss_cls.eta' in keys
+    m2 = O.build_model(O.r50_cfg(num_classes=7, depth=depth, head='SimpleLinear', loss='CrossEntropyLoss'))
+    assert [len(g['params']) for g in O.param_groups(m2, 0.01, 1e-4, 5.0)] == [1, 0, n_conv - 1, 0, n_bn_tensors, 1, 1]
+
+
+def test_r50_parameter_count_matches_metafile():
+    """configs/recognition/tsm/metafile.yml:15 (24 327 632 params at K=400) = 23 508 032 backbone + 2048*400+400."""
+    m = O.build_model(O.r50_cfg(num_classes=400, depth=50, head='SimpleLinear', loss='CrossEntropyLoss'))
+    n_backbone = sum(p.numel() for p in m.backbone.parameters())
+    n_head = sum(p.numel() for p in m.cls_head.fc_cls.parameters())
+    assert n_backbone == 23508032 and n_backbone + n_head == 24327632
+
+
+def test_bgmix_formula():
+    g = torch.Generator().manual_seed(0)
+    fr = torch.randint(0, 256, (2, 3, 5, 6, 3), generator=g, dtype=torch.uint8)
+    bg = torch.randint(0, 256, (2, 5, 6, 3), generator=g, dtype=torch.uint8)
+    out = O.bgmix_normalize(fr, bg, torch.tensor([True, False]), 0.5)
+    mean, std = torch.tensor(O.IMG_MEAN), torch.tensor(O.IMG_STD)
+    x = (fr.float() - mean) / std
+    b = (bg.float() - mean) / std
+    exp0 = (0.5 * x[0] + 0.5 * b[0][None]).permute(0, 3, 1, 2)
+    assert out.shape == (2, 3, 3, 5, 6)
+    assert torch.allclose(out[0], exp0, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(out[1], x[1].permute(0, 3, 1, 2), rtol=1e-5, atol=1e-5)
+
+
+def test_forward_shapes_and_b1_squeeze():
+    """Appendix C.3: labels.squeeze() turns a B=1 batch into a 0-d tensor; BaseHead.loss re-unsqueezes."""
+    m = O.build_model(O.r50_cfg(num_classes=5, depth=18, head='LocalSimilarityClassifier', loss='LSCLoss', dropout_ratio=0.0))
+    imgs = torch.randn(1, 8, 3, 32, 32)
+    out = m(imgs, torch.tensor([[3]]))
+    assert set(out) == {'top1_acc', 'top5_acc', 'loss_cls'} and out['loss_cls'].dim() == 0
+    m.eval()
+    with torch.no_grad():
+        p = m(imgs, return_loss=False)
+    assert p.shape == (1, 5) and abs(p.sum().item() - 1.0) < 1e-5          # average_clips='prob'
