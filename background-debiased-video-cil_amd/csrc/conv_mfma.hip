@@ -8,6 +8,7 @@
 // LDS image of both operands is k-major ([k][m], row stride BM+4 floats) so one MFMA operand
 // is one conflict-free ds_read_b32 (lane l reads [k = 2s + l/32][m = base + l%32]);
 // register-staged global->LDS double buffering with one barrier per K-step.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -26,18 +27,30 @@ __device__ __forceinline__ void mma_stage(const float* __restrict__ As, const fl
   const int r = lane & 31, h = lane >> 5;
   const float* ap = As + h * LDA + wm0 + r;
   const float* bp = Bs + h * LDB + wn0 + r;
+  // operand fragments are fetched one K-step ahead of the MFMAs that consume them
+  float a[2][TM], b[2][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a[0][i] = ap[32 * i];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b[0][j] = bp[32 * j];
 #pragma unroll
   for (int s = 0; s < BK / 2; ++s) {
-    float a[TM], b[TN];
+    const int cur = s & 1, nxt = cur ^ 1;
+    if (s + 1 < BK / 2) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[i] = ap[2 * s * LDA + 32 * i];
+      for (int i = 0; i < TM; ++i) a[nxt][i] = ap[2 * (s + 1) * LDA + 32 * i];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[j] = bp[2 * s * LDB + 32 * j];
+      for (int j = 0; j < TN; ++j) b[nxt][j] = bp[2 * (s + 1) * LDB + 32 * j];
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+    // pin the order: next step's LDS reads first, then this step's MFMAs (hipcc otherwise sinks the reads
+    // to just before their use and exposes the LDS latency every K-step)
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
   }
 }
 
@@ -74,24 +87,102 @@ __device__ __forceinline__ void store_direct(float* __restrict__ dst, const floa
 
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// ---- work decomposition -------------------------------------------------------------------
+// A launch covers `dp_tiles` whole output tiles (one block each, XCD-aware order) followed by `rem_tiles` tiles
+// whose K loop is cut into `split` slices (one block per slice, partial accumulators to a slab, summed in fixed
+// order by a fix-up kernel).  The host planner picks (dp_tiles, split) so that the block count is a multiple of
+// the number of co-resident blocks: on 256 CUs a tile count just above a multiple otherwise costs a whole extra
+// round (measured: 784 tiles -> 82 TFLOP/s, 768 or 1024 tiles -> 113-120).
+struct Work {
+  int dp_tiles, rem_tiles, split;
+};
+
+// bijective remap so that blocks b, b+8, b+16, ... (same XCD under round-robin dispatch) get consecutive tiles
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, j = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+struct WorkItem {
+  int tile, kb, ke, pslot;  // pslot < 0: whole tile, write the result; else partial-slab segment index
+};
+
+__device__ __forceinline__ WorkItem get_work(int b, const Work& wk, int nk) {
+  WorkItem it;
+  if (b < wk.dp_tiles) {
+    it.tile = xcd_remap(b, wk.dp_tiles);
+    it.kb = 0;
+    it.ke = nk;
+    it.pslot = -1;
+  } else {
+    const int rem = b - wk.dp_tiles;
+    const int rt = rem / wk.split, sl = rem - rt * wk.split;
+    it.tile = wk.dp_tiles + rt;
+    it.kb = (int)(((long long)sl * nk) / wk.split);
+    it.ke = (int)(((long long)(sl + 1) * nk) / wk.split);
+    it.pslot = wk.split > 1 ? rem : -1;
+  }
+  return it;
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void store_partial(float* __restrict__ slab, int pslot, const f32x16 (&acc)[TM][TN], int tid) {
+  float* base = slab + (size_t)pslot * (TM * TN * 16) * 256 + tid;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) base[(size_t)((i * TN + j) * 16 + e) * 256] = acc[i][j][e];
+}
+
+__device__ __forceinline__ void fprop_store(float* __restrict__ y, const Geom& g, int row, int col, float v) {
+  if (row < g.M) y[(size_t)row * g.Cout + col] = v;
+}
+
+// dgrad element store for stride 1: temporal un-shift scatter + optional masked residual add (see kernel comment)
+__device__ __forceinline__ void dgrad_store(float* __restrict__ dx, const float* __restrict__ add_src,
+                                            const float* __restrict__ add_mask, const Geom& g, int HW, int row, int n_hint,
+                                            bool have_n, int col, float v) {
+  const int cls = shift_class(col, g.fold);
+  int drow = row;
+  if (cls != 0) {
+    const int n = have_n ? n_hint : row / HW;
+    const int t = n % g.T;
+    if ((unsigned)(t + cls) < (unsigned)g.T) {
+      drow = row + cls * HW;
+    } else {
+      drow = row - cls * (g.T - 1) * HW;
+      v = 0.f;
+    }
+  }
+  const size_t o = (size_t)drow * g.Cin + col;
+  if (add_src != nullptr) {
+    float a = add_src[o];
+    if (add_mask != nullptr && !(add_mask[o] > 0.f)) a = 0.f;
+    v += a;
+  }
+  dx[o] = v;
+}
+
 // =========================================================================================
 // fprop: y[m, co] = sum_{tap, ci} x_shift[n, ho*st + r - p, wo*st + s - p, ci] * w[co, tap, ci]
 // =========================================================================================
 template <int BM, int BN, int WM, int WN, bool VEC_TAP>
 __global__ __launch_bounds__(256) void conv_fprop_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          float* __restrict__ y, Geom g, int MT, int NT) {
+                                                          float* __restrict__ y, Geom g, int NT, Work wk,
+                                                          float* __restrict__ slab) {
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 64, BP = BN / 64;
   constexpr int STAGE = BK * (LDA + LDB);
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); keep all the
-  // Cout-tiles of one activation row-tile on one XCD so the A tile is fetched into one L2 only.
-  const int id = blockIdx.x;
-  const int xcd = id & 7, jj = id >> 3;
-  const int mt = (jj / NT) * 8 + xcd, nt = jj % NT;
-  if (mt >= MT) return;
+  // Tile order: Cout-tile fastest, so the blocks that share an activation row-tile are consecutive and
+  // (through xcd_remap) land on one XCD / one L2.
+  const int nk = (g.Ktot + BK - 1) / BK;
+  const WorkItem it = get_work(blockIdx.x, wk, nk);
+  const int mt = it.tile / NT, nt = it.tile - mt * NT;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -124,9 +215,11 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const float* __restrict
       tap = k / g.Cin;
       c = k - tap * g.Cin;
     } else {
-      const int k0 = kt * BK;
-      tap = k0 / g.Cin;
-      c = k0 - tap * g.Cin + 4 * kg;
+      // tap-fastest K order: the R*S taps of one 16-channel chunk are consecutive K-steps, so the shifted
+      // re-reads of the same activation rows hit L1/L2 instead of going back to the fabric R*S times.
+      const int chunk = kt / RS;
+      tap = kt - chunk * RS;
+      c = chunk * BK + 4 * kg;
     }
     const int r = tap / g.S, s = tap - r * g.S;
     const bool kvalid = tap < RS;
@@ -139,7 +232,7 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const float* __restrict
       const size_t off = ((size_t)((a_n[p] + cls) * g.H + hi) * g.W + wi) * g.Cin + c;
       ra[p] = v ? *reinterpret_cast<const float4*>(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const int kb = kt * BK + 4 * kg;
+    const int kb = VEC_TAP ? kt * BK + 4 * kg : tap * g.Cin + c;
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
       const int co = nt * BN + arow + 64 * p;
@@ -162,30 +255,51 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const float* __restrict
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = (g.Ktot + BK - 1) / BK;
-  load(0);
+  load(it.kb);
   store(0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load(kt + 1);
+  for (int kt = it.kb; kt < it.ke; ++kt) {
+    const int cur = (kt - it.kb) & 1;
+    if (kt + 1 < it.ke) load(kt + 1);
     const float* As = smem + cur * STAGE;
     mma_stage<LDA, LDB, TM, TN>(As, As + BK * LDA, acc, wm0, wn0, lane);
-    if (kt + 1 < nk) store(cur ^ 1);
+    if (kt + 1 < it.ke) store(cur ^ 1);
     __syncthreads();
   }
 
+  if (it.pslot >= 0) {
+    store_partial<TM, TN>(slab, it.pslot, acc, tid);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = nt * BN + wn0 + 32 * j + (lane & 31);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
-        if (row < g.M) y[(size_t)row * g.Cout + col] = acc[i][j][e];
-      }
+      for (int e = 0; e < 16; ++e) fprop_store(y, g, mt * BM + wm0 + 32 * i + acc_row(e, lane), col, acc[i][j][e]);
     }
+}
+
+// fix-up for the K-split remainder tiles: sum the `split` partial accumulators in slice order, then the same
+// element store as the main kernel.  grid = (rem_tiles, NACC / 16), 256 threads mapped like the main kernel.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_fprop_fixup_kernel(const float* __restrict__ slab, float* __restrict__ y, Geom g,
+                                                                int NT, Work wk) {
+  constexpr int TN = BN / WN / 32;
+  constexpr int NACC = (BM / WM / 32) * TN * 16;
+  const int rt = blockIdx.x, tile = wk.dp_tiles + rt;
+  const int mt = tile / NT, nt = tile - mt * NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    const int f = blockIdx.y * 16 + q;
+    float v = 0.f;
+    for (int sl = 0; sl < wk.split; ++sl) v += slab[((size_t)(rt * wk.split + sl) * NACC + f) * 256 + tid];
+    const int e = f & 15, ij = f >> 4, i = ij / TN, j = ij - i * TN;
+    fprop_store(y, g, mt * BM + wm0 + 32 * i + acc_row(e, lane), nt * BN + wn0 + 32 * j + (lane & 31), v);
+  }
 }
 
 // =========================================================================================
@@ -197,7 +311,8 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const float* __restrict
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                           float* __restrict__ dx, const float* __restrict__ add_src,
-                                                          const float* __restrict__ add_mask, Geom g, int NT) {
+                                                          const float* __restrict__ add_mask, Geom g, int NT, Work wk,
+                                                          float* __restrict__ slab) {
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 64, BP = BN / 64;
@@ -216,10 +331,21 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict
   const int ns = s0 < g.S ? (g.S - s0 + st - 1) / st : 0;
   const int bh = (ph + g.pad - r0) / st, bw = (pw + g.pad - s0) / st;
 
-  const int id = blockIdx.x;
-  const int xcd = id & 7, jj = id >> 3;
-  const int mt = (jj / NT) * 8 + xcd, nt = jj % NT;
-  if (mt >= MT) return;
+  const int nk = nr * ns * g.Cout / BK;     // 0 for a class no filter tap reaches (e.g. 1x1 stride 2, odd pixels)
+  int mt, nt;
+  WorkItem it;
+  if (st == 1) {
+    it = get_work(blockIdx.x, wk, nk);
+    mt = it.tile / NT;
+    nt = it.tile - mt * NT;
+  } else {  // parity classes have different sizes: padded grid, no K split
+    const int id = blockIdx.x;
+    const int xcd = id & 7, jj = id >> 3;
+    mt = (jj / NT) * 8 + xcd;
+    nt = jj % NT;
+    if (mt >= MT) return;
+    it.tile = 0; it.kb = 0; it.ke = nk; it.pslot = -1;
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -246,9 +372,10 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict
 
   float4 ra[AP], rb[BP];
   auto load = [&](int kt) {
-    const int k0 = kt * BK;
-    const int ct = k0 / g.Cout;             // tap index inside this class
-    const int co0 = k0 - ct * g.Cout;
+    const int ntap = nr * ns;               // tap-fastest K order (see fprop)
+    const int chunk = kt / ntap;
+    const int ct = kt - chunk * ntap;       // tap index inside this class
+    const int co0 = chunk * BK;
     const int ir = ct / ns, is = ct - ir * ns;
     const int tap = (r0 + ir * st) * g.S + (s0 + is * st);
 #pragma unroll
@@ -281,19 +408,22 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = nr * ns * g.Cout / BK;     // 0 for a class no filter tap reaches (e.g. 1x1 stride 2, odd pixels)
-  if (nk > 0) {
-    load(0);
+  if (it.ke > it.kb) {
+    load(it.kb);
     store(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < nk) load(kt + 1);
+    for (int kt = it.kb; kt < it.ke; ++kt) {
+      const int cur = (kt - it.kb) & 1;
+      if (kt + 1 < it.ke) load(kt + 1);
       const float* As = smem + cur * STAGE;
       mma_stage<LDA, LDB, TM, TN>(As, As + BK * LDA, acc, wm0, wn0, lane);
-      if (kt + 1 < nk) store(cur ^ 1);
+      if (kt + 1 < it.ke) store(cur ^ 1);
       __syncthreads();
     }
+  }
+  if (it.pslot >= 0) {
+    store_partial<TM, TN>(slab, it.pslot, acc, tid);
+    return;
   }
 
   // Epilogue.  Forward read xs[frame n] = x[frame n + cls]; so the gradient of row m goes to
@@ -306,41 +436,39 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict
     for (int e = 0; e < 16; ++e) {
       const int mrow = mt * BM + wm0 + 32 * i + acc_row(e, lane);
       if (mrow >= Mc) continue;
-      int row, n;
-      if (st == 1) {
-        row = mrow;
-        n = 0;
-      } else {
+      int row = mrow, n = 0;
+      if (st != 1) {
         n = mrow / HcWc;
         const int rem = mrow - n * HcWc;
         const int hc = rem / Wc;
         row = (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
       }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = nt * BN + wn0 + 32 * j + (lane & 31);
-        const int cls = shift_class(col, g.fold);
-        float v = acc[i][j][e];
-        int drow = row;
-        if (cls != 0) {
-          if (st == 1) n = row / HW;
-          const int t = n % g.T;
-          if ((unsigned)(t + cls) < (unsigned)g.T) {
-            drow = row + cls * HW;
-          } else {
-            drow = row - cls * (g.T - 1) * HW;
-            v = 0.f;
-          }
-        }
-        const size_t o = (size_t)drow * g.Cin + col;
-        if (add_src != nullptr) {
-          float a = add_src[o];
-          if (add_mask != nullptr && !(add_mask[o] > 0.f)) a = 0.f;
-          v += a;
-        }
-        dx[o] = v;
-      }
+      for (int j = 0; j < TN; ++j)
+        dgrad_store(dx, add_src, add_mask, g, HW, row, n, st != 1, nt * BN + wn0 + 32 * j + (lane & 31), acc[i][j][e]);
     }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_dgrad_fixup_kernel(const float* __restrict__ slab, float* __restrict__ dx,
+                                                                const float* __restrict__ add_src,
+                                                                const float* __restrict__ add_mask, Geom g, int NT, Work wk) {
+  constexpr int TN = BN / WN / 32;
+  constexpr int NACC = (BM / WM / 32) * TN * 16;
+  const int rt = blockIdx.x, tile = wk.dp_tiles + rt;
+  const int mt = tile / NT, nt = tile - mt * NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int HW = g.H * g.W;
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    const int f = blockIdx.y * 16 + q;
+    float v = 0.f;
+    for (int sl = 0; sl < wk.split; ++sl) v += slab[((size_t)(rt * wk.split + sl) * NACC + f) * 256 + tid];
+    const int e = f & 15, ij = f >> 4, i = ij / TN, j = ij - i * TN;
+    const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
+    if (row < g.M) dgrad_store(dx, add_src, add_mask, g, HW, row, 0, false, nt * BN + wn0 + 32 * j + (lane & 31), v);
+  }
 }
 
 // =========================================================================================
@@ -525,13 +653,73 @@ Geom make_geom(const bdv_conv_geom* g) {
   return d;
 }
 
+// ---- host-side planning ---------------------------------------------------------------------
+
+bool debug_plan() {
+  static const bool on = getenv("BDVCIL_DEBUG_PLAN") != nullptr;
+  return on;
+}
+
+// number of co-resident 256-thread blocks of `kernel` on the whole device (occupancy API x CU count)
+template <class KernelT>
+int resident_blocks(KernelT kernel) {
+  int dev = 0, cus = 256, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 768;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, 256, 0) != hipSuccess || per_cu <= 0) {
+    (void)hipGetLastError();
+    per_cu = 3;
+  }
+  return cus * per_cu;
+}
+
+// Pick the K-split of the remainder tiles.  A CU is MFMA-bound once it holds >= 3 blocks, so the launch time is
+// set by the CU with the most work: whole rounds of `cus` tiles run data-parallel, the last partial round
+// (r < cus tiles) is cut along K into `split` slices per tile so that its blocks spread over all CUs.
+// Cost model in microseconds: one K-iteration of a 64-accumulator block = 0.85 us of one CU's MFMA pipes;
+// a CU with 1 / 2 blocks reaches ~65 % / ~85 % of that rate; the fix-up moves 2 x seg_bytes per slice, mostly
+// through the Infinity Cache (~8 TB/s).
+Work plan_work(int tiles, int nk, int W, size_t seg_bytes, size_t ws_bytes) {
+  const int cus = 256;
+  (void)W;
+  Work wk;
+  const int q = tiles / cus, r = tiles - q * cus;
+  wk.dp_tiles = tiles;
+  wk.rem_tiles = 0;
+  wk.split = 1;
+  if (r == 0 || nk < 8) return wk;
+  auto eff = [&](int c) { return (q + c) >= 3 ? 1.0 : ((q + c) == 2 ? 0.85 : 0.65); };
+  double best = 1e30;
+  int best_s = 1;
+  for (int sp = 1; sp <= 32 && nk / sp >= 4; ++sp) {
+    const size_t need = (size_t)r * sp * seg_bytes;
+    if (sp > 1 && need > ws_bytes) break;
+    const int c = (int)(((long long)r * sp + cus - 1) / cus);
+    double cost = c * ((double)nk / sp) * 0.85 / eff(c);
+    if (sp > 1) cost += 4.0 + (double)need * 2.0 / 8.0e6;
+    if (cost < best * 0.95) {  // prefer fewer slices unless clearly better
+      best = cost;
+      best_s = sp;
+    }
+  }
+  if (best_s > 1) {
+    wk.dp_tiles = q * cus;
+    wk.rem_tiles = r;
+    wk.split = best_s;
+  }
+  return wk;
+}
+
+constexpr size_t kSegBytes128 = 64 * 256 * sizeof(float);  // 128x128 or 256x64 tile: 64 accumulator regs x 256 threads
+constexpr size_t kMaxSplitWorkspace = 160ull << 20;
+
 struct WgradPlan {
   bool small;  // 64x64 tiles
   bool vec_tap;
   int MTw, NTw, splits, kt_per_split;
 };
 
-WgradPlan plan_wgrad(const bdv_conv_geom* g) {
+WgradPlan plan_wgrad(const bdv_conv_geom* g, int W) {
   WgradPlan p;
   p.vec_tap = (g->Cin % BK) != 0;
   p.small = p.vec_tap || (g->Cout % 128) != 0 || (g->Cin % 128) != 0;
@@ -542,53 +730,155 @@ WgradPlan plan_wgrad(const bdv_conv_geom* g) {
   const int64_t M = (int64_t)g->N * g->Ho * g->Wo;
   const int nkt = (int)((M + BK - 1) / BK);
   const int tiles = p.MTw * p.NTw;
-  int splits = (1536 + tiles - 1) / tiles;
-  if (splits > 512) splits = 512;
-  int per = (nkt + splits - 1) / splits;
-  if (per < 8) per = 8;
+  // blocks = tiles * splits should fill whole rounds of W co-resident blocks; more rounds = less slab traffic per
+  // flop is not true here (slab bytes grow with splits), so take the smallest round count whose fill is >= 90 %.
+  int best_s = 1;
+  double best_cost = 1e30;
+  const double dw_bytes = (double)g->Cout * ktot * 4.0;
+  for (int k = 1; k <= 4; ++k) {
+    int sp = (int)(((long long)k * W) / tiles);
+    if (sp < 1) sp = 1;
+    if (sp > 1024) sp = 1024;
+    while (sp > 1 && (nkt + sp - 1) / sp < 8) --sp;
+    const int per = (nkt + sp - 1) / sp;
+    const double rounds = (double)(((long long)tiles * sp + W - 1) / W);
+    const double t_iter = 0.85 * ((double)W / 256.0) * (p.small ? 0.3 : 1.0);
+    const double cost = rounds * per * t_iter + 4.0 + sp * dw_bytes / 4.0e6;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best_s = sp;
+    }
+  }
+  int per = (nkt + best_s - 1) / best_s;
   p.kt_per_split = per;
   p.splits = (nkt + per - 1) / per;
   return p;
 }
 
+int wgrad_resident(const bdv_conv_geom* g) {
+  const bool vec_tap = (g->Cin % BK) != 0;
+  const bool small = vec_tap || (g->Cout % 128) != 0 || (g->Cin % 128) != 0;
+  static const int w_big = resident_blocks(conv_wgrad_kernel<128, 128, 2, 2, false>);
+  static const int w_small = resident_blocks(conv_wgrad_kernel<64, 64, 2, 2, false>);
+  return small ? w_small : w_big;
+}
+
+struct FdPlan {
+  bool wide;  // 128x128 tile (else 256x64)
+  int MT, NT, nk, W;
+  Work wk;
+};
+
+FdPlan plan_fprop(const Geom& g, size_t ws_bytes) {
+  FdPlan p;
+  p.wide = (g.Cout % 128) == 0;
+  const int bm = p.wide ? 128 : 256, bn = p.wide ? 128 : 64;
+  p.MT = (g.M + bm - 1) / bm;
+  p.NT = g.Cout / bn;
+  p.nk = (g.Ktot + BK - 1) / BK;
+  const bool vec_tap = (g.Cin % BK) != 0;
+  static const int w0 = resident_blocks(conv_fprop_kernel<128, 128, 2, 2, false>);
+  static const int w1 = resident_blocks(conv_fprop_kernel<256, 64, 4, 1, false>);
+  static const int w2 = resident_blocks(conv_fprop_kernel<256, 64, 4, 1, true>);
+  p.W = p.wide ? w0 : (vec_tap ? w2 : w1);
+  p.wk = plan_work(p.MT * p.NT, p.nk, p.W, kSegBytes128, ws_bytes);
+  return p;
+}
+
+FdPlan plan_dgrad(const Geom& g, size_t ws_bytes) {
+  FdPlan p;
+  p.wide = (g.Cin % 128) == 0;
+  const int bm = p.wide ? 128 : 256, bn = p.wide ? 128 : 64;
+  const int st = g.stride;
+  const int Mc0 = g.N * ((g.H + st - 1) / st) * ((g.W + st - 1) / st);  // largest parity class
+  p.MT = (Mc0 + bm - 1) / bm;
+  p.NT = g.Cin / bn;
+  p.nk = g.R * g.S * g.Cout / BK;
+  static const int w0 = resident_blocks(conv_dgrad_kernel<128, 128, 2, 2>);
+  static const int w1 = resident_blocks(conv_dgrad_kernel<256, 64, 4, 1>);
+  p.W = p.wide ? w0 : w1;
+  if (st == 1) {
+    p.wk = plan_work(p.MT * p.NT, p.nk, p.W, kSegBytes128, ws_bytes);
+  } else {
+    p.wk.dp_tiles = ((p.MT + 7) / 8) * 8 * p.NT;  // padded grid per parity class
+    p.wk.rem_tiles = 0;
+    p.wk.split = 1;
+  }
+  return p;
+}
+
 }  // namespace
 
-extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* gg, void* stream) {
+extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
+  if (check_geom(gg, "bdv_conv_workspace_bytes")) return 0;
+  if (kind == 2) {
+    const WgradPlan p = plan_wgrad(gg, wgrad_resident(gg));
+    return (size_t)p.splits * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(float);
+  }
+  Geom g = make_geom(gg);
+  FdPlan p;
+  if (kind == 0) {
+    g.M = g.N * g.Ho * g.Wo;
+    g.Ktot = g.R * g.S * g.Cin;
+    p = plan_fprop(g, kMaxSplitWorkspace);
+  } else {
+    if (gg->Cin % 64 != 0) return 0;
+    g.M = g.N * g.H * g.W;
+    g.Ktot = g.R * g.S * g.Cout;
+    p = plan_dgrad(g, kMaxSplitWorkspace);
+  }
+  const size_t need = p.wk.split > 1 ? (size_t)p.wk.rem_tiles * p.wk.split * kSegBytes128 : 0;
+  return need > 16 ? need : 16;
+}
+
+extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* gg, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_fprop")) return e;
   BDV_REQUIRE(x && w && y, "bdv_conv_fprop: null pointer");
-  BDV_REQUIRE(bdv_aligned16(x) && bdv_aligned16(w) && bdv_aligned16(y), "bdv_conv_fprop: pointers must be 16-byte aligned");
+  BDV_REQUIRE(bdv_aligned16(x) && bdv_aligned16(w) && bdv_aligned16(y) && bdv_aligned16(workspace),
+              "bdv_conv_fprop: pointers must be 16-byte aligned");
   Geom g = make_geom(gg);
   g.M = g.N * g.Ho * g.Wo;
   g.Ktot = g.R * g.S * g.Cin;
   hipStream_t s = (hipStream_t)stream;
   const bool vec_tap = (g.Cin % BK) != 0;
   BDV_REQUIRE(!(vec_tap && g.fold > 0), "bdv_conv_fprop: shift needs Cin %% 16 == 0");
-  if (g.Cout % 128 == 0) {
-    constexpr int BM = 128, BN = 128;
-    const int MT = (g.M + BM - 1) / BM, NT = g.Cout / BN;
-    const int grid = ((MT + 7) / 8) * 8 * NT;
+  const FdPlan p = plan_fprop(g, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0);
+  const int blocks = p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split;
+  float* slab = (float*)workspace;
+  if (debug_plan())
+    fprintf(stderr, "[bdv plan] fprop %dx%d Cin %d Cout %d k%d s%d: tiles %d nk %d W %d -> dp %d rem %d split %d\n", g.H, g.W,
+            g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.W, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
+  if (p.wide) {
     if (vec_tap)
-      hipLaunchKernelGGL((conv_fprop_kernel<BM, BN, 2, 2, true>), dim3(grid), dim3(256), 0, s, x, w, y, g, MT, NT);
+      hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2, true>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab);
     else
-      hipLaunchKernelGGL((conv_fprop_kernel<BM, BN, 2, 2, false>), dim3(grid), dim3(256), 0, s, x, w, y, g, MT, NT);
+      hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2, false>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab);
   } else {
-    constexpr int BM = 256, BN = 64;
-    const int MT = (g.M + BM - 1) / BM, NT = g.Cout / BN;
-    const int grid = ((MT + 7) / 8) * 8 * NT;
     if (vec_tap)
-      hipLaunchKernelGGL((conv_fprop_kernel<BM, BN, 4, 1, true>), dim3(grid), dim3(256), 0, s, x, w, y, g, MT, NT);
+      hipLaunchKernelGGL((conv_fprop_kernel<256, 64, 4, 1, true>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab);
     else
-      hipLaunchKernelGGL((conv_fprop_kernel<BM, BN, 4, 1, false>), dim3(grid), dim3(256), 0, s, x, w, y, g, MT, NT);
+      hipLaunchKernelGGL((conv_fprop_kernel<256, 64, 4, 1, false>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab);
   }
   BDV_LAUNCH_CHECK("bdv_conv_fprop");
+  if (p.wk.split > 1) {
+    const dim3 fg(p.wk.rem_tiles, 4);
+    if (p.wide)
+      hipLaunchKernelGGL((conv_fprop_fixup_kernel<128, 128, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk);
+    else
+      hipLaunchKernelGGL((conv_fprop_fixup_kernel<256, 64, 4, 1>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk);
+    BDV_LAUNCH_CHECK("bdv_conv_fprop(fixup)");
+  }
   return BDV_OK;
 }
 
 extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const float* add_src,
-                              const float* add_mask_src, const bdv_conv_geom* gg, void* stream) {
+                              const float* add_mask_src, const bdv_conv_geom* gg, void* workspace, size_t workspace_bytes,
+                              void* stream) {
   if (int e = check_geom(gg, "bdv_conv_dgrad")) return e;
   BDV_REQUIRE(dy && w && dx, "bdv_conv_dgrad: null pointer");
-  BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(w) && bdv_aligned16(dx), "bdv_conv_dgrad: pointers must be 16-byte aligned");
+  BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(w) && bdv_aligned16(dx) && bdv_aligned16(workspace),
+              "bdv_conv_dgrad: pointers must be 16-byte aligned");
   BDV_REQUIRE(gg->Cin % 64 == 0, "bdv_conv_dgrad: Cin=%d must be a multiple of 64", gg->Cin);
   BDV_REQUIRE(add_src != nullptr || add_mask_src == nullptr, "bdv_conv_dgrad: add_mask_src without add_src");
   Geom g = make_geom(gg);
@@ -596,26 +886,26 @@ extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const 
   g.Ktot = g.R * g.S * g.Cout;
   hipStream_t s = (hipStream_t)stream;
   const int st = g.stride;
-  const int Mc0 = g.N * ((g.H + st - 1) / st) * ((g.W + st - 1) / st);   // largest parity class
-  if (g.Cin % 128 == 0) {
-    constexpr int BM = 128, BN = 128;
-    const int MT = (Mc0 + BM - 1) / BM, NT = g.Cin / BN;
-    const dim3 grid(((MT + 7) / 8) * 8 * NT, st * st);
-    hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, NT);
-  } else {
-    constexpr int BM = 256, BN = 64;
-    const int MT = (Mc0 + BM - 1) / BM, NT = g.Cin / BN;
-    const dim3 grid(((MT + 7) / 8) * 8 * NT, st * st);
-    hipLaunchKernelGGL((conv_dgrad_kernel<BM, BN, 4, 1>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, NT);
-  }
+  const FdPlan p = plan_dgrad(g, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0);
+  const dim3 grid(p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split, st * st);
+  float* slab = (float*)workspace;
+  if (debug_plan())
+    fprintf(stderr, "[bdv plan] dgrad %dx%d Cin %d Cout %d k%d s%d: tiles %d nk %d W %d -> dp %d rem %d split %d\n", g.H, g.W,
+            g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.W, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
+  if (p.wide)
+    hipLaunchKernelGGL((conv_dgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, p.NT, p.wk, slab);
+  else
+    hipLaunchKernelGGL((conv_dgrad_kernel<256, 64, 4, 1>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, p.NT, p.wk, slab);
   BDV_LAUNCH_CHECK("bdv_conv_dgrad");
+  if (p.wk.split > 1) {
+    const dim3 fg(p.wk.rem_tiles, 4);
+    if (p.wide)
+      hipLaunchKernelGGL((conv_dgrad_fixup_kernel<128, 128, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, dx, add_src, add_mask_src, g, p.NT, p.wk);
+    else
+      hipLaunchKernelGGL((conv_dgrad_fixup_kernel<256, 64, 4, 1>), fg, dim3(256), 0, s, (const float*)slab, dx, add_src, add_mask_src, g, p.NT, p.wk);
+    BDV_LAUNCH_CHECK("bdv_conv_dgrad(fixup)");
+  }
   return BDV_OK;
-}
-
-extern "C" size_t bdv_conv_wgrad_workspace_bytes(const bdv_conv_geom* g) {
-  if (check_geom(g, "bdv_conv_wgrad_workspace_bytes")) return 0;
-  const WgradPlan p = plan_wgrad(g);
-  return (size_t)p.splits * g->Cout * g->R * g->S * g->Cin * sizeof(float);
 }
 
 extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float beta, const bdv_conv_geom* gg,
@@ -624,8 +914,8 @@ extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float 
   BDV_REQUIRE(dy && x && dw && workspace, "bdv_conv_wgrad: null pointer");
   BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(dw) && bdv_aligned16(workspace),
               "bdv_conv_wgrad: pointers must be 16-byte aligned");
-  const WgradPlan p = plan_wgrad(gg);
-  const size_t need = bdv_conv_wgrad_workspace_bytes(gg);
+  const WgradPlan p = plan_wgrad(gg, wgrad_resident(gg));
+  const size_t need = (size_t)p.splits * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(float);
   if (workspace_bytes < need) {
     bdv_set_error("bdv_conv_wgrad: workspace %zu < required %zu bytes", workspace_bytes, need);
     return BDV_EWORKSPACE;
@@ -637,6 +927,10 @@ extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float 
   hipStream_t s = (hipStream_t)stream;
   float* slab = (float*)workspace;
   const dim3 grid(p.MTw * p.NTw, p.splits);
+  if (debug_plan())
+    fprintf(stderr, "[bdv plan] wgrad %dx%d Cin %d Cout %d k%d s%d: tiles %d W %d -> splits %d x %d k-iters (%s)\n", gg->H, gg->W,
+            gg->Cin, gg->Cout, gg->R, gg->stride, p.MTw * p.NTw, wgrad_resident(gg), p.splits, p.kt_per_split,
+            p.small ? "64x64" : "128x128");
   if (!p.small) {
     hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,
                        p.kt_per_split);

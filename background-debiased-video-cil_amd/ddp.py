@@ -101,6 +101,8 @@ class GradAllReducer:
         b.ensure()
         on_gpu = b.flat.is_cuda
         if on_gpu:
+            from .functional import join_side_stream
+            join_side_stream(b.flat.device)         # weight gradients are produced on the wgrad side stream
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=b.flat.device)
             ready = torch.cuda.Event()

@@ -21,6 +21,59 @@ import torch
 from . import kernels as K
 
 
+# ---------------------------------------------------------------------------------------------
+# side stream for weight gradients
+# ---------------------------------------------------------------------------------------------
+# In backward, wgrad(l) only feeds the optimizer while dgrad(l) -> BN-backward(l-1) -> ... is the critical chain.
+# Launching the wgrads on a second HIP stream keeps two independent kernels in flight, so the CUs a kernel's last
+# partial wave of workgroups leaves idle (tile-count quantisation on 256 CUs) are filled by the other kernel, and the
+# HBM-bound BN-backward passes overlap the MFMA-bound wgrad.  ``join_side_stream`` must run before gradients are
+# consumed (FusedSGD.step / clip / GradAllReducer / StemFn.backward do it).
+import os as _os
+_SIDE = {'enabled': _os.environ.get('BDVCIL_WGRAD_SIDE_STREAM', '1') != '0', 'streams': {}, 'pending': {}}
+
+
+def set_side_stream_enabled(flag: bool):
+    _SIDE['enabled'] = bool(flag)
+
+
+def _side_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE['streams'].get(idx)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE['streams'][idx] = st
+    return idx, st
+
+
+def join_side_stream(device=None):
+    """Make the current stream wait for every wgrad launched on the side stream so far."""
+    for idx, ev in list(_SIDE['pending'].items()):
+        if device is None or (device.index if device.index is not None else torch.cuda.current_device()) == idx:
+            torch.cuda.current_stream(idx).wait_event(ev)
+            del _SIDE['pending'][idx]
+
+
+def wgrad_overlapped(dy: torch.Tensor, inp: torch.Tensor, geom) -> torch.Tensor:
+    """conv_wgrad on the side stream (same result tensor semantics as K.conv_wgrad)."""
+    if not _SIDE['enabled']:
+        return K.conv_wgrad(dy, inp, geom)
+    main = torch.cuda.current_stream(dy.device)
+    idx, side = _side_stream(dy.device)
+    dw = torch.empty((geom.Cout, geom.R, geom.S, geom.Cin), dtype=torch.float32, device=dy.device)   # owned by main
+    ready = torch.cuda.Event()
+    ready.record(main)
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        K.conv_wgrad(dy, inp, geom, dw=dw, beta=0.0, ws_tag='wgrad_side')
+        done = torch.cuda.Event()
+        done.record(side)
+    for t in (dy, inp, dw):
+        t.record_stream(side)
+    _SIDE['pending'][idx] = done
+    return dw
+
+
 def nhwc_to_nchw_view(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, 3, 1, 2)
 
@@ -92,6 +145,7 @@ class StemFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw4 = K.conv_wgrad(dy, x4, ctx.g)
             dw = dw4[..., :3].permute(0, 3, 1, 2)
+        join_side_stream(dp.device)          # the stem is the last backward node: all wgrads are visible after it
         return None, dw, dgamma, dbeta, None, None
 
 
@@ -171,7 +225,7 @@ class ResBlockFn(torch.autograd.Function):
             grads[3 * i + 1], grads[3 * i + 2] = dg, db
             inp = acts[i - 1] if i > 0 else x
             if need[3 + 3 * i]:
-                grads[3 * i] = K.conv_wgrad(dy, inp, ctx.geoms[i]).permute(0, 3, 1, 2)
+                grads[3 * i] = wgrad_overlapped(dy, inp, ctx.geoms[i]).permute(0, 3, 1, 2)
             if i > 0:
                 d = K.conv_dgrad(dy, weight_krsc(wt), ctx.geoms[i])
                 mask_out = acts[i - 1]
@@ -187,7 +241,7 @@ class ResBlockFn(torch.autograd.Function):
             dyd, dgd, dbd = K.bn_backward(dout, out, yd, gd, mean_d, invstd_d, True)
             grads[3 * n_main + 1], grads[3 * n_main + 2] = dgd, dbd
             if need[3 + 3 * n_main]:
-                grads[3 * n_main] = K.conv_wgrad(dyd, x, gdn).permute(0, 3, 1, 2)
+                grads[3 * n_main] = wgrad_overlapped(dyd, x, gdn).permute(0, 3, 1, 2)
             if need_dx:
                 dx_id = K.conv_dgrad(dyd, weight_krsc(wd), gdn)
                 dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), ctx.geoms[0], add_src=dx_id)

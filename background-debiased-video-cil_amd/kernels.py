@@ -57,18 +57,28 @@ def make_geom(N, H, W, Cin, Cout, R, S, stride, pad, T=1, fold=0) -> ConvGeom:
 # convolution
 # ---------------------------------------------------------------------------------------------
 
-def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def _conv_ws(g: ConvGeom, kind: int, device, tag: str) -> torch.Tensor:
+    need = lib().bdv_conv_workspace_bytes(ctypes.byref(g), kind)
+    if need == 0:
+        check(-1, 'bdv_conv_workspace_bytes')
+    return workspace(need, device, tag)
+
+
+def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torch.Tensor] = None,
+               ws_tag: str = 'conv') -> torch.Tensor:
     """x (N,H,W,Cin) NHWC, w (Cout,R,S,Cin) -> y (N,Ho,Wo,Cout)."""
     _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
     _chk(w, (g.Cout, g.R, g.S, g.Cin), name='w')
     y = out if out is not None else torch.empty((g.N, g.Ho, g.Wo, g.Cout), dtype=torch.float32, device=x.device)
     _chk(y, (g.N, g.Ho, g.Wo, g.Cout), name='y')
-    check(lib().bdv_conv_fprop(_p(x), _p(w), _p(y), ctypes.byref(g), _stream()), 'bdv_conv_fprop')
+    ws = _conv_ws(g, 0, x.device, ws_tag)
+    check(lib().bdv_conv_fprop(_p(x), _p(w), _p(y), ctypes.byref(g), _p(ws), ws.numel(), _stream()), 'bdv_conv_fprop')
     return y
 
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional[torch.Tensor] = None,
-               add_mask_src: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               add_mask_src: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+               ws_tag: str = 'conv') -> torch.Tensor:
     _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
     _chk(w, (g.Cout, g.R, g.S, g.Cin), name='w')
     dx = out if out is not None else torch.empty((g.N, g.H, g.W, g.Cin), dtype=torch.float32, device=dy.device)
@@ -79,23 +89,21 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
             raise ValueError('conv_dgrad: in-place add_src is not allowed with a temporal shift (scatter epilogue)')
     if add_mask_src is not None:
         _chk(add_mask_src, (g.N, g.H, g.W, g.Cin), name='add_mask_src')
-    check(lib().bdv_conv_dgrad(_p(dy), _p(w), _p(dx), _p(add_src), _p(add_mask_src), ctypes.byref(g), _stream()),
-          'bdv_conv_dgrad')
+    ws = _conv_ws(g, 1, dy.device, ws_tag)
+    check(lib().bdv_conv_dgrad(_p(dy), _p(w), _p(dx), _p(add_src), _p(add_mask_src), ctypes.byref(g), _p(ws), ws.numel(),
+                               _stream()), 'bdv_conv_dgrad')
     return dx
 
 
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, dw: Optional[torch.Tensor] = None,
-               beta: float = 0.0) -> torch.Tensor:
+               beta: float = 0.0, ws_tag: str = 'wgrad') -> torch.Tensor:
     _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
     _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
     if dw is None:
         dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
         beta = 0.0
     _chk(dw, (g.Cout, g.R, g.S, g.Cin), name='dw')
-    need = lib().bdv_conv_wgrad_workspace_bytes(ctypes.byref(g))
-    if need == 0:
-        check(-1, 'bdv_conv_wgrad_workspace_bytes')
-    ws = workspace(need, dy.device, 'wgrad')
+    ws = _conv_ws(g, 2, dy.device, ws_tag)
     check(lib().bdv_conv_wgrad(_p(dy), _p(x), _p(dw), float(beta), ctypes.byref(g), _p(ws), ws.numel(), _stream()),
           'bdv_conv_wgrad')
     return dw

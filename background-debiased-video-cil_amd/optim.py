@@ -17,6 +17,7 @@ from torch.nn.modules.batchnorm import _BatchNorm
 from torch.nn.modules.conv import _ConvNd
 
 from . import kernels as K
+from .functional import join_side_stream
 from .heads import LSC, IncrementalNet
 from .losses import LSCLoss
 from .registry import OPTIMIZER_BUILDERS, build_from_cfg
@@ -86,6 +87,7 @@ class FusedSGD(torch.optim.Optimizer):
         active = self._active()
         if not active:
             return None
+        join_side_stream()
         t = self._build_tables(active)
         K.multi_sqnorm(t['g'], t['n'], len(active), self._sqnorm)
         K.clip_coef(self._sqnorm, self._grad_scale, float(max_norm), self._coef)
@@ -104,6 +106,7 @@ class FusedSGD(torch.optim.Optimizer):
         momenta = {g['momentum'] for g in self.param_groups}
         if len(momenta) != 1:
             raise NotImplementedError('FusedSGD: one momentum value for all groups')
+        join_side_stream()
         t = self._build_tables(active)
         K.multi_sgd(t['p'], t['g'], t['b'], t['n'], t['lr'], t['wd'], len(active), momenta.pop(), self._grad_scale,
                     self._coef if self._clip_active else None)

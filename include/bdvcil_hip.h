@@ -51,18 +51,24 @@ int bdv_abi_version(void);
 /* ---- convolution = implicit GEMM on v_mfma_f32_32x32x2_f32 --------------------------------
  * fprop replaces F.conv2d inside ConvModule (+ UPSTREAM TemporalShift.shift when fold > 0:
  * channels [0,fold) read frame t+1, [fold,2fold) read frame t-1, zero at clip ends).
- * x [N,H,W,Cin], w [Cout,R,S,Cin], y [N,Ho,Wo,Cout]. */
-int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* g, void* stream);
+ * x [N,H,W,Cin], w [Cout,R,S,Cin], y [N,Ho,Wo,Cout].
+ *
+ * Workspaces: bdv_conv_workspace_bytes(g, kind) with kind 0 = fprop, 1 = dgrad, 2 = wgrad.  fprop/dgrad use it
+ * for the K-split partial accumulators of the remainder tiles (tile counts that do not fill whole rounds of
+ * co-resident workgroups on the 256 CUs); passing NULL disables the split (correct, slower on such shapes). */
+size_t bdv_conv_workspace_bytes(const bdv_conv_geom* g, int kind);
+int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* g, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* dgrad: dx[N,H,W,Cin] = unshift(conv_transpose(dy, w)) + (add_src ? add_src * mask : 0),
  * mask = (add_mask_src > 0) when add_mask_src != NULL (fused ReLU-backward of the identity path).
  * Replaces autograd of F.conv2d w.r.t. its input and of TemporalShift.shift. */
 int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const float* add_src,
-                   const float* add_mask_src, const bdv_conv_geom* g, void* stream);
+                   const float* add_mask_src, const bdv_conv_geom* g, void* workspace, size_t workspace_bytes,
+                   void* stream);
 
 /* wgrad: dw[Cout,R,S,Cin] = beta * dw + sum_pixels dy (x) shift(x).  Deterministic split-K:
  * partial slabs go to `workspace`, a second kernel reduces them in fixed order. */
-size_t bdv_conv_wgrad_workspace_bytes(const bdv_conv_geom* g);
 int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float beta, const bdv_conv_geom* g,
                    void* workspace, size_t workspace_bytes, void* stream);
 
