@@ -133,11 +133,28 @@ __global__ void bn_eval_params_kernel(int C, const float* __restrict__ gamma, co
 }
 
 // ---- apply -------------------------------------------------------------------------------
+// ReLU sign mask: bit e of mask[] = (out[e] > 0) for flat element index e (one uint32 per 32 channels).
+// Backward kernels read this 1-bit-per-element mask instead of re-reading the fp32 activation.
+__device__ __forceinline__ unsigned nibble_gt0(const float4& o) {
+  return (o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u);
+}
+__device__ __forceinline__ unsigned mask_nibble(const uint32_t* __restrict__ mask, int64_t i4) {
+  return (mask[i4 >> 3] >> (4 * (int)(i4 & 7))) & 0xFu;
+}
+__device__ __forceinline__ float4 apply_nibble(float4 g, unsigned nib) {
+  g.x = (nib & 1u) ? g.x : 0.f;
+  g.y = (nib & 2u) ? g.y : 0.f;
+  g.z = (nib & 4u) ? g.z : 0.f;
+  g.w = (nib & 8u) ? g.w : 0.f;
+  return g;
+}
+
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
                                                         const float4* __restrict__ shift, const float4* __restrict__ res,
-                                                        float4* __restrict__ out, int64_t n4, int CV) {
+                                                        float4* __restrict__ out, uint32_t* __restrict__ mask, int64_t n4, int CV) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // n4 is a multiple of 8 (C % 32 == 0) and so is the stride: the 8 lanes of one mask word stay together
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const int c4 = (int)(i % CV);
     const float4 v = y[i], sc = scale[c4], sh = shift[c4];
@@ -151,6 +168,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
     if (RELU) {
+      if (mask != nullptr) {
+        unsigned m = nibble_gt0(o) << (4 * (threadIdx.x & 7));
+        m |= __shfl_xor(m, 1, 64);
+        m |= __shfl_xor(m, 2, 64);
+        m |= __shfl_xor(m, 4, 64);
+        if ((threadIdx.x & 7) == 0) mask[i >> 3] = m;
+      }
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
     out[i] = o;
@@ -159,7 +183,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
 
 // ---- backward ----------------------------------------------------------------------------
 template <bool RELU>
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dout, const uint32_t* __restrict__ mask,
                                                               const float* __restrict__ y, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* __restrict__ p1,
                                                               float* __restrict__ p2, int64_t M, int C, int CVB, int RL,
@@ -178,13 +202,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   for (int64_t r = r0 + rl; r < r1; r += RL) {
     const int64_t i = r * CV + c4;
     float4 g = reinterpret_cast<const float4*>(dout)[i];
-    if (RELU) {
-      const float4 o = reinterpret_cast<const float4*>(out)[i];
-      g.x = o.x > 0.f ? g.x : 0.f;
-      g.y = o.y > 0.f ? g.y : 0.f;
-      g.z = o.z > 0.f ? g.z : 0.f;
-      g.w = o.w > 0.f ? g.w : 0.f;
-    }
+    if (RELU) g = apply_nibble(g, mask_nibble(mask, i));
     const float4 v = reinterpret_cast<const float4*>(y)[i];
     s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
     s2.x += g.x * ((v.x - mu.x) * is.x);
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 template <bool RELU>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restrict__ dout, const float4* __restrict__ out,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restrict__ dout, const uint32_t* __restrict__ mask,
                                                             const float4* __restrict__ y, const float4* __restrict__ mean,
                                                             const float4* __restrict__ invstd, const float4* __restrict__ coef,
                                                             float4* __restrict__ dy, int64_t n4, int CV) {
@@ -232,13 +250,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const int c4 = (int)(i % CV);
     float4 g = dout[i];
-    if (RELU) {
-      const float4 o = out[i];
-      g.x = o.x > 0.f ? g.x : 0.f;
-      g.y = o.y > 0.f ? g.y : 0.f;
-      g.z = o.z > 0.f ? g.z : 0.f;
-      g.w = o.w > 0.f ? g.w : 0.f;
-    }
+    if (RELU) g = apply_nibble(g, mask_nibble(mask, i));
     const float4 v = y[i], mu = mean[c4], is = invstd[c4];
     const float4 a = coef[c4], b = coef[CV + c4], c = coef[2 * CV + c4];
     float4 d;
@@ -250,16 +262,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void relu_bwd_kernel(const float4* __restrict__ dout, const float4* __restrict__ out,
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float4* __restrict__ dout, const uint32_t* __restrict__ mask,
                                                         const float4* __restrict__ add, float4* __restrict__ g, int64_t n4) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 d = dout[i];
-    const float4 o = out[i];
-    d.x = o.x > 0.f ? d.x : 0.f;
-    d.y = o.y > 0.f ? d.y : 0.f;
-    d.z = o.z > 0.f ? d.z : 0.f;
-    d.w = o.w > 0.f ? d.w : 0.f;
+    float4 d = apply_nibble(dout[i], mask_nibble(mask, i));
     if (add != nullptr) {
       const float4 a = add[i];
       d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
@@ -325,10 +332,11 @@ extern "C" int bdv_bn_eval_params(int C, const float* gamma, const float* beta, 
   return BDV_OK;
 }
 
-extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shift, const float* res, float* out, int64_t M,
-                            int C, int relu, void* stream) {
+extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shift, const float* res, float* out,
+                            uint32_t* relu_mask, int64_t M, int C, int relu, void* stream) {
   BDV_REQUIRE(y && scale && shift && out, "bdv_bn_apply: null pointer");
   BDV_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bdv_bn_apply: bad shape");
+  BDV_REQUIRE(relu_mask == nullptr || (relu && C % 32 == 0), "bdv_bn_apply: relu_mask needs relu and C %% 32 == 0");
   BDV_REQUIRE(bdv_aligned16(y) && bdv_aligned16(out) && bdv_aligned16(scale) && bdv_aligned16(shift) &&
                   (res == nullptr || bdv_aligned16(res)), "bdv_bn_apply: alignment");
   const int64_t n4 = M * C / 4;
@@ -337,20 +345,20 @@ extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shi
   const dim3 grid(ew_grid(n4)), blk(256);
   const float4 *y4 = (const float4*)y, *sc = (const float4*)scale, *sh = (const float4*)shift, *r4 = (const float4*)res;
   float4* o4 = (float4*)out;
-  if (relu && res) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, blk, 0, s, y4, sc, sh, r4, o4, n4, CV);
-  else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, blk, 0, s, y4, sc, sh, r4, o4, n4, CV);
-  else if (res) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, blk, 0, s, y4, sc, sh, r4, o4, n4, CV);
-  else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, blk, 0, s, y4, sc, sh, r4, o4, n4, CV);
+  if (relu && res) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, blk, 0, s, y4, sc, sh, r4, o4, relu_mask, n4, CV);
+  else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, blk, 0, s, y4, sc, sh, r4, o4, relu_mask, n4, CV);
+  else if (res) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, blk, 0, s, y4, sc, sh, r4, o4, relu_mask, n4, CV);
+  else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, blk, 0, s, y4, sc, sh, r4, o4, relu_mask, n4, CV);
   BDV_LAUNCH_CHECK("bdv_bn_apply");
   return BDV_OK;
 }
 
-extern "C" int bdv_bn_backward(const float* dout, const float* out, const float* y, const float* gamma,
+extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, const float* y, const float* gamma,
                                const float* save_mean, const float* save_invstd, float* dy, float* dgamma, float* dbeta,
                                float beta_acc, int64_t M, int C, int relu, void* workspace, size_t workspace_bytes,
                                void* stream) {
   BDV_REQUIRE(dout && y && gamma && save_mean && save_invstd && dy && workspace, "bdv_bn_backward: null pointer");
-  BDV_REQUIRE(!relu || out, "bdv_bn_backward: relu needs the forward output");
+  BDV_REQUIRE(!relu || (relu_mask && C % 32 == 0), "bdv_bn_backward: relu needs the forward ReLU mask (C %% 32 == 0)");
   BDV_REQUIRE(M > 0 && bn_c_ok(C), "bdv_bn_backward: unsupported M=%lld C=%d", (long long)M, C);
   BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(y) && bdv_aligned16(dy) && bdv_aligned16(workspace) &&
                   bdv_aligned16(save_mean) && bdv_aligned16(save_invstd), "bdv_bn_backward: alignment");
@@ -364,10 +372,10 @@ extern "C" int bdv_bn_backward(const float* dout, const float* out, const float*
   float* coef = p2 + MAX_RB_TIMES_C;
   hipStream_t s = (hipStream_t)stream;
   if (relu)
-    hipLaunchKernelGGL((bn_bwd_partial_kernel<true>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, out, y, save_mean, save_invstd,
+    hipLaunchKernelGGL((bn_bwd_partial_kernel<true>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean, save_invstd,
                        p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
   else
-    hipLaunchKernelGGL((bn_bwd_partial_kernel<false>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, out, y, save_mean, save_invstd,
+    hipLaunchKernelGGL((bn_bwd_partial_kernel<false>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean, save_invstd,
                        p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
   BDV_LAUNCH_CHECK("bdv_bn_backward(partial)");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)p1, (const float*)p2, b.RB,
@@ -376,21 +384,21 @@ extern "C" int bdv_bn_backward(const float* dout, const float* out, const float*
   const int64_t n4 = M * C / 4;
   const dim3 grid(ew_grid(n4)), blk(256);
   if (relu)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), grid, blk, 0, s, (const float4*)dout, (const float4*)out, (const float4*)y,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), grid, blk, 0, s, (const float4*)dout, relu_mask, (const float4*)y,
                        (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy, n4, C / 4);
   else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, blk, 0, s, (const float4*)dout, (const float4*)out, (const float4*)y,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, blk, 0, s, (const float4*)dout, relu_mask, (const float4*)y,
                        (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy, n4, C / 4);
   BDV_LAUNCH_CHECK("bdv_bn_backward(apply)");
   return BDV_OK;
 }
 
-extern "C" int bdv_relu_bwd(const float* dout, const float* out, const float* add, float* g, int64_t numel, void* stream) {
-  BDV_REQUIRE(dout && out && g && numel > 0 && numel % 4 == 0, "bdv_relu_bwd: bad argument");
-  BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(out) && bdv_aligned16(g) && (!add || bdv_aligned16(add)), "bdv_relu_bwd: alignment");
+extern "C" int bdv_relu_bwd(const float* dout, const uint32_t* relu_mask, const float* add, float* g, int64_t numel, void* stream) {
+  BDV_REQUIRE(dout && relu_mask && g && numel > 0 && numel % 32 == 0, "bdv_relu_bwd: bad argument");
+  BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(g) && (!add || bdv_aligned16(add)), "bdv_relu_bwd: alignment");
   const int64_t n4 = numel / 4;
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout,
-                     (const float4*)out, (const float4*)add, (float4*)g, n4);
+                     relu_mask, (const float4*)add, (float4*)g, n4);
   BDV_LAUNCH_CHECK("bdv_relu_bwd");
   return BDV_OK;
 }

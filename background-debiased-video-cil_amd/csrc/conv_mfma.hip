@@ -142,7 +142,7 @@ __device__ __forceinline__ void fprop_store(float* __restrict__ y, const Geom& g
 
 // dgrad element store for stride 1: temporal un-shift scatter + optional masked residual add (see kernel comment)
 __device__ __forceinline__ void dgrad_store(float* __restrict__ dx, const float* __restrict__ add_src,
-                                            const float* __restrict__ add_mask, const Geom& g, int HW, int row, int n_hint,
+                                            const uint32_t* __restrict__ add_mask, const Geom& g, int HW, int row, int n_hint,
                                             bool have_n, int col, float v) {
   const int cls = shift_class(col, g.fold);
   int drow = row;
@@ -159,7 +159,7 @@ __device__ __forceinline__ void dgrad_store(float* __restrict__ dx, const float*
   const size_t o = (size_t)drow * g.Cin + col;
   if (add_src != nullptr) {
     float a = add_src[o];
-    if (add_mask != nullptr && !(add_mask[o] > 0.f)) a = 0.f;
+    if (add_mask != nullptr && !((add_mask[o >> 5] >> (o & 31)) & 1u)) a = 0.f;
     v += a;
   }
   dx[o] = v;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void conv_fprop_fixup_kernel(const float* __re
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                           float* __restrict__ dx, const float* __restrict__ add_src,
-                                                          const float* __restrict__ add_mask, Geom g, int NT, Work wk,
+                                                          const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk,
                                                           float* __restrict__ slab) {
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_dgrad_fixup_kernel(const float* __restrict__ slab, float* __restrict__ dx,
                                                                 const float* __restrict__ add_src,
-                                                                const float* __restrict__ add_mask, Geom g, int NT, Work wk) {
+                                                                const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk) {
   constexpr int TN = BN / WN / 32;
   constexpr int NACC = (BM / WM / 32) * TN * 16;
   const int rt = blockIdx.x, tile = wk.dp_tiles + rt;
@@ -873,7 +873,7 @@ extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bd
 }
 
 extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const float* add_src,
-                              const float* add_mask_src, const bdv_conv_geom* gg, void* workspace, size_t workspace_bytes,
+                              const uint32_t* add_mask_src, const bdv_conv_geom* gg, void* workspace, size_t workspace_bytes,
                               void* stream) {
   if (int e = check_geom(gg, "bdv_conv_dgrad")) return e;
   BDV_REQUIRE(dy && w && dx, "bdv_conv_dgrad: null pointer");

@@ -125,22 +125,27 @@ class StemFn(torch.autograd.Function):
         w4[..., :3] = weight.detach().permute(0, 2, 3, 1)           # 37 KB repack, plumbing
         y = K.conv_fprop(x4, w4, g)
         mean, invstd, scale, shift = _bn_forward(y, bn, gamma, beta, training)
-        a = K.bn_apply(y, scale, shift, None, True)
+        save = training and any(ctx.needs_input_grad)
+        if save:
+            a, mask = K.bn_apply(y, scale, shift, None, True, want_mask=True)
+        else:
+            a, mask = K.bn_apply(y, scale, shift, None, True, out=y), None
         p, idx = K.maxpool_fwd(a)
         ctx.g = g
         ctx.bn_training = training
-        if training and any(ctx.needs_input_grad):
-            ctx.save_for_backward(x4, gamma, y, a, idx, mean, invstd)
+        ctx.a_shape = tuple(a.shape)
+        if save:
+            ctx.save_for_backward(x4, gamma, y, mask, idx, mean, invstd)
         return p
 
     @staticmethod
     def backward(ctx, dp):
         if not ctx.bn_training:
             raise NotImplementedError('backward through eval-mode BatchNorm is not implemented (norm_eval=False in all CIL configs)')
-        x4, gamma, y, a, idx, mean, invstd = ctx.saved_tensors
+        x4, gamma, y, mask, idx, mean, invstd = ctx.saved_tensors
         dp = dp if dp.is_contiguous() else dp.contiguous()
-        da = K.maxpool_bwd(dp, idx, tuple(a.shape))
-        dy, dgamma, dbeta = K.bn_backward(da, a, y, gamma, mean, invstd, True)
+        da = K.maxpool_bwd(dp, idx, ctx.a_shape)
+        dy, dgamma, dbeta = K.bn_backward(da, mask, y, gamma, mean, invstd, True)
         dw = None
         if ctx.needs_input_grad[1]:
             dw4 = K.conv_wgrad(dy, x4, ctx.g)
@@ -182,9 +187,11 @@ class ResBlockFn(torch.autograd.Function):
             y = K.conv_fprop(cur, weight_krsc(wt), g)
             mean, invstd, sc, sh = _bn_forward(y, bns[i], gm, bt, training)
             last = i == n_main - 1
-            a = K.bn_apply(y, sc, sh, identity if last else None, True if last else u.relu)
             if save:
-                saved += [y, a, mean, invstd]
+                a, mask = K.bn_apply(y, sc, sh, identity if last else None, True, want_mask=True)
+                saved += [y, a, mean, invstd, mask]
+            else:
+                a = K.bn_apply(y, sc, sh, identity if last else None, True)
             cur = a
             h, w_ = g.Ho, g.Wo
         if save:
@@ -207,38 +214,38 @@ class ResBlockFn(torch.autograd.Function):
         saved, params = t[:ctx.n_saved], t[ctx.n_saved:]
         n_main, has_down = ctx.n_main, ctx.has_down
         x = saved[0]
-        ys = [saved[1 + 4 * i] for i in range(n_main)]
-        acts = [saved[2 + 4 * i] for i in range(n_main)]
-        means = [saved[3 + 4 * i] for i in range(n_main)]
-        invstds = [saved[4 + 4 * i] for i in range(n_main)]
-        out = acts[-1]
+        ys = [saved[1 + 5 * i] for i in range(n_main)]
+        acts = [saved[2 + 5 * i] for i in range(n_main)]
+        means = [saved[3 + 5 * i] for i in range(n_main)]
+        invstds = [saved[4 + 5 * i] for i in range(n_main)]
+        masks = [saved[5 + 5 * i] for i in range(n_main)]
+        out_mask = masks[-1]
         dout = dout if dout.is_contiguous() else dout.contiguous()
         need = ctx.needs_input_grad      # (x, blk, training, *params)
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
         need_dx = need[0]
 
         # main branch, last unit first.  ``d`` is the gradient w.r.t. the unit's (post-ReLU) output.
-        d, mask_out = dout, out
+        d = dout
         for i in range(n_main - 1, -1, -1):
             wt, gm = params[3 * i], params[3 * i + 1]
-            dy, dg, db = K.bn_backward(d, mask_out, ys[i], gm, means[i], invstds[i], True)
+            dy, dg, db = K.bn_backward(d, masks[i], ys[i], gm, means[i], invstds[i], True)
             grads[3 * i + 1], grads[3 * i + 2] = dg, db
             inp = acts[i - 1] if i > 0 else x
             if need[3 + 3 * i]:
                 grads[3 * i] = wgrad_overlapped(dy, inp, ctx.geoms[i]).permute(0, 3, 1, 2)
             if i > 0:
                 d = K.conv_dgrad(dy, weight_krsc(wt), ctx.geoms[i])
-                mask_out = acts[i - 1]
             else:
                 dy_first = dy
 
         dx = None
         if has_down:
-            yd, mean_d, invstd_d = saved[1 + 4 * n_main:4 + 4 * n_main]
+            yd, mean_d, invstd_d = saved[1 + 5 * n_main:4 + 5 * n_main]
             wd, gd = params[3 * n_main], params[3 * n_main + 1]
             gdn = ctx.geoms[n_main]
             # gradient entering the downsample BN is dout * (out > 0): same mask as the block output
-            dyd, dgd, dbd = K.bn_backward(dout, out, yd, gd, mean_d, invstd_d, True)
+            dyd, dgd, dbd = K.bn_backward(dout, out_mask, yd, gd, mean_d, invstd_d, True)
             grads[3 * n_main + 1], grads[3 * n_main + 2] = dgd, dbd
             if need[3 + 3 * n_main]:
                 grads[3 * n_main] = wgrad_overlapped(dyd, x, gdn).permute(0, 3, 1, 2)
@@ -247,7 +254,7 @@ class ResBlockFn(torch.autograd.Function):
                 dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), ctx.geoms[0], add_src=dx_id)
         elif need_dx:
             # identity path: dout * (out > 0), fused into the conv1 dgrad epilogue
-            dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), ctx.geoms[0], add_src=dout, add_mask_src=out)
+            dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), ctx.geoms[0], add_src=dout, add_mask_src=out_mask)
         return (dx, None, None, *grads)
 
 

@@ -88,7 +88,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
         if add_src.data_ptr() == dx.data_ptr() and g.fold > 0:
             raise ValueError('conv_dgrad: in-place add_src is not allowed with a temporal shift (scatter epilogue)')
     if add_mask_src is not None:
-        _chk(add_mask_src, (g.N, g.H, g.W, g.Cin), name='add_mask_src')
+        _chk(add_mask_src, (g.N * g.H * g.W * g.Cin // 32,), dtype=torch.int32, name='add_mask_src')
     ws = _conv_ws(g, 1, dy.device, ws_tag)
     check(lib().bdv_conv_dgrad(_p(dy), _p(w), _p(dx), _p(add_src), _p(add_mask_src), ctypes.byref(g), _p(ws), ws.numel(),
                                _stream()), 'bdv_conv_dgrad')
@@ -145,7 +145,8 @@ def bn_eval_params(gamma, beta, running_mean, running_var, eps):
     return ss[0], ss[1]
 
 
-def bn_apply(y, scale, shift, res=None, relu=True, out=None):
+def bn_apply(y, scale, shift, res=None, relu=True, out=None, want_mask=False):
+    """-> out, or (out, relu_mask) when want_mask (int32 tensor, 1 bit per element: out > 0)."""
     C = y.shape[-1]
     M = y.numel() // C
     _chk(y, name='y')
@@ -155,18 +156,24 @@ def bn_apply(y, scale, shift, res=None, relu=True, out=None):
         _chk(res, tuple(y.shape), name='res')
     o = out if out is not None else torch.empty_like(y)
     _chk(o, tuple(y.shape), name='out')
-    check(lib().bdv_bn_apply(_p(y), _p(scale), _p(shift), _p(res), _p(o), M, C, int(bool(relu)), _stream()), 'bdv_bn_apply')
-    return o
+    mask = None
+    if want_mask:
+        if not relu or C % 32 != 0:
+            raise ValueError('bn_apply: a ReLU mask needs relu=True and C % 32 == 0')
+        mask = torch.empty(y.numel() // 32, dtype=torch.int32, device=y.device)
+    check(lib().bdv_bn_apply(_p(y), _p(scale), _p(shift), _p(res), _p(o), _p(mask), M, C, int(bool(relu)), _stream()),
+          'bdv_bn_apply')
+    return (o, mask) if want_mask else o
 
 
-def bn_backward(dout, out, y, gamma, save_mean, save_invstd, relu, dgamma=None, dbeta=None, beta_acc=0.0, dy=None):
-    """Returns (dy, dgamma, dbeta).  ``out`` is the forward output (needed only when relu)."""
+def bn_backward(dout, relu_mask, y, gamma, save_mean, save_invstd, relu, dgamma=None, dbeta=None, beta_acc=0.0, dy=None):
+    """Returns (dy, dgamma, dbeta).  ``relu_mask`` is the bit mask from ``bn_apply(want_mask=True)`` (needed when relu)."""
     C = y.shape[-1]
     M = y.numel() // C
     _chk(dout, tuple(y.shape), name='dout')
     _chk(y, name='y')
     if relu:
-        _chk(out, tuple(y.shape), name='out')
+        _chk(relu_mask, (y.numel() // 32,), dtype=torch.int32, name='relu_mask')
     for t, n in ((gamma, 'gamma'), (save_mean, 'save_mean'), (save_invstd, 'save_invstd')):
         _chk(t, (C,), name=n)
     if dgamma is None:
@@ -178,20 +185,20 @@ def bn_backward(dout, out, y, gamma, save_mean, save_invstd, relu, dgamma=None, 
     d = dy if dy is not None else torch.empty_like(y)
     _chk(d, tuple(y.shape), name='dy')
     ws = _bn_ws(M, C, y.device)
-    check(lib().bdv_bn_backward(_p(dout), _p(out if relu else None), _p(y), _p(gamma), _p(save_mean), _p(save_invstd),
+    check(lib().bdv_bn_backward(_p(dout), _p(relu_mask if relu else None), _p(y), _p(gamma), _p(save_mean), _p(save_invstd),
                                 _p(d), _p(dgamma), _p(dbeta), float(beta_acc), M, C, int(bool(relu)), _p(ws), ws.numel(),
                                 _stream()), 'bdv_bn_backward')
     return d, dgamma, dbeta
 
 
-def relu_bwd(dout, out, add=None, g=None):
+def relu_bwd(dout, relu_mask, add=None, g=None):
     _chk(dout, name='dout')
-    _chk(out, tuple(dout.shape), name='out')
+    _chk(relu_mask, (dout.numel() // 32,), dtype=torch.int32, name='relu_mask')
     if add is not None:
         _chk(add, tuple(dout.shape), name='add')
     r = g if g is not None else torch.empty_like(dout)
     _chk(r, tuple(dout.shape), name='g')
-    check(lib().bdv_relu_bwd(_p(dout), _p(out), _p(add), _p(r), dout.numel(), _stream()), 'bdv_relu_bwd')
+    check(lib().bdv_relu_bwd(_p(dout), _p(relu_mask), _p(add), _p(r), dout.numel(), _stream()), 'bdv_relu_bwd')
     return r
 
 

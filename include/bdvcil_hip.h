@@ -61,10 +61,11 @@ int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom
                    size_t workspace_bytes, void* stream);
 
 /* dgrad: dx[N,H,W,Cin] = unshift(conv_transpose(dy, w)) + (add_src ? add_src * mask : 0),
- * mask = (add_mask_src > 0) when add_mask_src != NULL (fused ReLU-backward of the identity path).
+ * mask = bit e of add_mask_src (the ReLU sign mask written by bdv_bn_apply) when add_mask_src != NULL
+ * (fused ReLU-backward of the identity path).
  * Replaces autograd of F.conv2d w.r.t. its input and of TemporalShift.shift. */
 int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const float* add_src,
-                   const float* add_mask_src, const bdv_conv_geom* g, void* workspace, size_t workspace_bytes,
+                   const uint32_t* add_mask_src, const bdv_conv_geom* g, void* workspace, size_t workspace_bytes,
                    void* stream);
 
 /* wgrad: dw[Cout,R,S,Cin] = beta * dw + sum_pixels dy (x) shift(x).  Deterministic split-K:
@@ -86,19 +87,21 @@ int bdv_bn_train_stats(const float* y, int64_t M, int C, const float* gamma, con
 /* eval: scale/shift from running statistics. */
 int bdv_bn_eval_params(int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, void* stream);
-/* out = act(y*scale[c] + shift[c] + (res ? res : 0)), act = ReLU if relu != 0. */
+/* out = act(y*scale[c] + shift[c] + (res ? res : 0)), act = ReLU if relu != 0.  relu_mask (optional, needs
+ * C % 32 == 0): bit e of relu_mask[] = (out[e] > 0) for flat element index e -- the 1-bit-per-element ReLU sign
+ * mask the backward kernels read instead of the fp32 activation. */
 int bdv_bn_apply(const float* y, const float* scale, const float* shift, const float* res, float* out,
-                 int64_t M, int C, int relu, void* stream);
-/* backward of (BN-train -> +res -> ReLU): g = dout * (out > 0 if relu), dgamma = sum g*xhat,
+                 uint32_t* relu_mask, int64_t M, int C, int relu, void* stream);
+/* backward of (BN-train -> +res -> ReLU): g = dout * (relu_mask bit if relu), dgamma = sum g*xhat,
  * dbeta = sum g, dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).  dgamma/dbeta are written as
  * beta_acc*old + new.  The residual-path gradient is g itself; consumers re-derive it from
- * (dout, out) -- see bdv_conv_dgrad(add_src, add_mask_src) and bdv_relu_bwd. */
-int bdv_bn_backward(const float* dout, const float* out, const float* y, const float* gamma,
+ * (dout, relu_mask) -- see bdv_conv_dgrad(add_src, add_mask_src) and bdv_relu_bwd. */
+int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, const float* y, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dy, float* dgamma,
                     float* dbeta, float beta_acc, int64_t M, int C, int relu, void* workspace,
                     size_t workspace_bytes, void* stream);
-/* g = dout * (out > 0) (+ add) : masked gradient for an identity path that has no conv behind it */
-int bdv_relu_bwd(const float* dout, const float* out, const float* add, float* g, int64_t numel, void* stream);
+/* g = dout * relu_mask (+ add) : masked gradient for an identity path that has no conv behind it */
+int bdv_relu_bwd(const float* dout, const uint32_t* relu_mask, const float* add, float* g, int64_t numel, void* stream);
 /* out = a + b (gradient junctions) */
 int bdv_add(const float* a, const float* b, float* out, int64_t numel, void* stream);
 

@@ -79,8 +79,12 @@ def test_dgrad(case, with_add, dev):
         add = torch.randn(N, H, W, Cin, generator=gen)
         mask = torch.randn(N, H, W, Cin, generator=gen)
         ref = ref + (add * (mask > 0)).permute(0, 3, 1, 2)
+    bits = None
+    if mask is not None:      # the 1-bit-per-element ReLU sign mask layout written by bdv_bn_apply
+        import numpy as np
+        bits = torch.from_numpy(np.packbits((mask > 0).numpy().reshape(-1), bitorder='little').view(np.int32).copy()).to(dev)
     dx = K.conv_dgrad(dy.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), g,
-                      add_src=None if add is None else add.to(dev), add_mask_src=None if mask is None else mask.to(dev))
+                      add_src=None if add is None else add.to(dev), add_mask_src=bits)
     torch.cuda.synchronize()
     _close(dx.cpu().permute(0, 3, 1, 2), ref)
 

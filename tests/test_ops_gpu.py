@@ -44,20 +44,26 @@ def test_bn_train_fwd_bwd(M, C, relu, res, dev):
     yd, gd, bd = y.detach().to(dev), gamma.detach().to(dev), beta.detach().to(dev)
     rmd, rvd = rm.to(dev), rv.to(dev)
     mean, invstd, scale, shift = K.bn_train_stats(yd, gd, bd, 1e-5, 0.1, rmd, rvd)
-    out = K.bn_apply(yd, scale, shift, None if r is None else r.to(dev), relu)
+    mask = None
+    if relu:
+        out, mask = K.bn_apply(yd, scale, shift, None if r is None else r.to(dev), True, want_mask=True)
+        bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder='little').astype(bool).reshape(M, C)
+        assert np.array_equal(bits, (o.detach() > 0).numpy())            # 1 bit per element: out > 0
+    else:
+        out = K.bn_apply(yd, scale, shift, None if r is None else r.to(dev), False)
     _close(out, o)
     _close(rmd, rm_ref)
     _close(rvd, rv_ref)
-    dy, dg, db = K.bn_backward(dout.to(dev), out, yd, gd, mean, invstd, relu)
+    dy, dg, db = K.bn_backward(dout.to(dev), mask, yd, gd, mean, invstd, relu)
     _close(dy, y.grad, tol=2e-5)
     _close(dg, gamma.grad, tol=2e-5, atol=1e-4)
     _close(db, beta.grad, tol=2e-5, atol=1e-4)
     # accumulate into existing dgamma/dbeta
-    _, dg2, db2 = K.bn_backward(dout.to(dev), out, yd, gd, mean, invstd, relu, dgamma=dg.clone(), dbeta=db.clone(), beta_acc=1.0)
+    _, dg2, db2 = K.bn_backward(dout.to(dev), mask, yd, gd, mean, invstd, relu, dgamma=dg.clone(), dbeta=db.clone(), beta_acc=1.0)
     _close(dg2, 2 * gamma.grad, tol=2e-5, atol=2e-4)
     # residual-path gradient helper
     if relu:
-        gmask = K.relu_bwd(dout.to(dev), out)
+        gmask = K.relu_bwd(dout.to(dev), mask)
         _close(gmask, dout * (o > 0))
 
 
