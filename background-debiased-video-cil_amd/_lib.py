@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -34,11 +34,13 @@ SIGNATURES = {
     'bdv_last_error': (c_char_p, []),
     'bdv_abi_version': (c_int, []),
     'bdv_conv_workspace_bytes': (c_size_t, [POINTER(ConvGeom), c_int]),
-    'bdv_conv_fprop': (c_int, [P, P, P, POINTER(ConvGeom), P, c_size_t, P]),
+    'bdv_conv_fprop_stat_rows': (c_int, [POINTER(ConvGeom)]),
+    'bdv_conv_fprop': (c_int, [P, P, P, POINTER(ConvGeom), P, P, c_size_t, P]),
     'bdv_conv_dgrad': (c_int, [P, P, P, P, P, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_conv_wgrad': (c_int, [P, P, P, c_float, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_bn_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'bdv_bn_train_stats': (c_int, [P, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_size_t, P]),
+    'bdv_bn_train_finalize': (c_int, [P, c_int, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P]),
     'bdv_bn_eval_params': (c_int, [c_int, P, P, P, P, c_float, P, P, P]),
     'bdv_bn_apply': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, P]),
     'bdv_bn_backward': (c_int, [P, P, P, P, P, P, P, P, P, c_float, c_int64, c_int, c_int, P, c_size_t, P]),

@@ -69,24 +69,24 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-// Fixed-order column sum of a [RB][C] fp32 slab in fp64: 16 channels x 16 row-lanes per block.
+// Fixed-order column sum of two [RB][C] fp32 slabs in fp64: 4 channels x 64 row-lanes per block.
 __device__ __forceinline__ void slab_colsum2(const float* __restrict__ a, const float* __restrict__ b, int RB, int C, int c,
-                                             int rl, double (*sh)[16][17], double& sa, double& sb) {
+                                             int rl, double (*sh)[64][5], double& sa, double& sb) {
   double x = 0.0, y = 0.0;
   if (c < C) {
-    for (int r = rl; r < RB; r += 16) {
+    for (int r = rl; r < RB; r += 64) {
       x += (double)a[(int64_t)r * C + c];
       y += (double)b[(int64_t)r * C + c];
     }
   }
-  const int cl = threadIdx.x & 15;
+  const int cl = threadIdx.x & 3;
   sh[0][rl][cl] = x;
   sh[1][rl][cl] = y;
   __syncthreads();
   sa = 0.0;
   sb = 0.0;
   if (rl == 0) {
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < 64; ++k) {
       sa += sh[0][k][cl];
       sb += sh[1][k][cl];
     }
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                            float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double sh[2][16][17];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
+  __shared__ double sh[2][64][5];
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3), rl = threadIdx.x >> 2;
   double s, q;
   slab_colsum2(psum, psq, RB, C, c, rl, sh, s, q);
   if (rl != 0 || c >= C) return;
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                                int64_t M, int C, const float* __restrict__ gamma,
                                                                const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float beta_acc, float* __restrict__ coef) {
-  __shared__ double sh[2][16][17];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
+  __shared__ double sh[2][64][5];
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3), rl = threadIdx.x >> 2;
   double s1, s2;
   slab_colsum2(p1, p2, RB, C, c, rl, sh, s1, s2);
   if (rl != 0 || c >= C) return;
@@ -317,9 +317,22 @@ extern "C" int bdv_bn_train_stats(const float* y, int64_t M, int C, const float*
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_partial_kernel, dim3(b.RB, b.CC), dim3(256), 0, s, y, psum, psq, M, C, b.CVB, b.RL, b.rows_per_block);
   BDV_LAUNCH_CHECK("bdv_bn_train_stats(partial)");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)psum, (const float*)psq, b.RB,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)psum, (const float*)psq, b.RB,
                      M, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
   BDV_LAUNCH_CHECK("bdv_bn_train_stats(finalize)");
+  return BDV_OK;
+}
+
+extern "C" int bdv_bn_train_finalize(const float* partial, int rows, int64_t M, int C, const float* gamma, const float* beta,
+                                     float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                                     float* save_invstd, float* scale, float* shift, void* stream) {
+  BDV_REQUIRE(partial && gamma && beta && save_mean && save_invstd && scale && shift, "bdv_bn_train_finalize: null pointer");
+  BDV_REQUIRE(rows > 0 && M > 0 && C > 0 && C % 4 == 0, "bdv_bn_train_finalize: bad shape");
+  BDV_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bdv_bn_train_finalize: running stats must come in pairs");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial,
+                     partial + (size_t)rows * C, rows, M, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
+                     save_invstd, scale, shift);
+  BDV_LAUNCH_CHECK("bdv_bn_train_finalize");
   return BDV_OK;
 }
 
@@ -378,7 +391,7 @@ extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, con
     hipLaunchKernelGGL((bn_bwd_partial_kernel<false>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean, save_invstd,
                        p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
   BDV_LAUNCH_CHECK("bdv_bn_backward(partial)");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)p1, (const float*)p2, b.RB,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)p1, (const float*)p2, b.RB,
                      M, C, gamma, save_invstd, dgamma, dbeta, beta_acc, coef);
   BDV_LAUNCH_CHECK("bdv_bn_backward(finalize)");
   const int64_t n4 = M * C / 4;

@@ -165,13 +165,48 @@ __device__ __forceinline__ void dgrad_store(float* __restrict__ dx, const float*
   dx[o] = v;
 }
 
+// BatchNorm batch statistics fused into the fprop epilogue: per tile, the column sums of y and y^2 over the
+// tile's valid rows -> bn_partial[0][mt][co], bn_partial[1][mt][co]; a fixed-order fp64 finalize sums the MT rows.
+// cs/cq hold this lane's sums over its accumulator registers for each of its TN columns.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void tile_colstats(float* __restrict__ smem, float (&cs)[BN / WN / 32], float (&cq)[BN / WN / 32],
+                                              float* __restrict__ bn_partial, int MT, int Cout, int mt, int nt, int tid) {
+  constexpr int TN = BN / WN / 32;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn0 = (wave % WN) * (BN / WN);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {  // lanes l and l+32 hold the same column, different rows
+    cs[j] += __shfl_xor(cs[j], 32, 64);
+    cq[j] += __shfl_xor(cq[j], 32, 64);
+  }
+  __syncthreads();  // every wave is done with the operand stages in LDS
+  if (lane < 32) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      smem[wm * BN + wn0 + 32 * j + lane] = cs[j];
+      smem[(WM + wm) * BN + wn0 + 32 * j + lane] = cq[j];
+    }
+  }
+  __syncthreads();
+  if (tid < BN) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < WM; ++k) {
+      a += smem[k * BN + tid];
+      b += smem[(WM + k) * BN + tid];
+    }
+    bn_partial[(size_t)mt * Cout + nt * BN + tid] = a;
+    bn_partial[((size_t)MT + mt) * Cout + nt * BN + tid] = b;
+  }
+}
+
 // =========================================================================================
 // fprop: y[m, co] = sum_{tap, ci} x_shift[n, ho*st + r - p, wo*st + s - p, ci] * w[co, tap, ci]
 // =========================================================================================
 template <int BM, int BN, int WM, int WN, bool VEC_TAP>
 __global__ __launch_bounds__(256) void conv_fprop_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           float* __restrict__ y, Geom g, int NT, Work wk,
-                                                          float* __restrict__ slab) {
+                                                          float* __restrict__ slab, float* __restrict__ bn_partial, int MT) {
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 64, BP = BN / 64;
@@ -271,35 +306,69 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const float* __restrict
     store_partial<TM, TN>(slab, it.pslot, acc, tid);
     return;
   }
+  float cs[TN], cq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) cs[j] = cq[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = nt * BN + wn0 + 32 * j + (lane & 31);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) fprop_store(y, g, mt * BM + wm0 + 32 * i + acc_row(e, lane), col, acc[i][j][e]);
+      for (int e = 0; e < 16; ++e) {
+        const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
+        const float v = acc[i][j][e];
+        fprop_store(y, g, row, col, v);
+        if (row < g.M) {
+          cs[j] += v;
+          cq[j] += v * v;
+        }
+      }
     }
+  if (bn_partial != nullptr)
+    tile_colstats<BM, BN, WM, WN>(smem, cs, cq, bn_partial, MT, g.Cout, mt, nt, tid);
 }
 
 // fix-up for the K-split remainder tiles: sum the `split` partial accumulators in slice order, then the same
-// element store as the main kernel.  grid = (rem_tiles, NACC / 16), 256 threads mapped like the main kernel.
+// element store (and BN column statistics) as the main kernel.  grid = rem_tiles, 256 threads mapped like the
+// main kernel.
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_fprop_fixup_kernel(const float* __restrict__ slab, float* __restrict__ y, Geom g,
-                                                                int NT, Work wk) {
-  constexpr int TN = BN / WN / 32;
-  constexpr int NACC = (BM / WM / 32) * TN * 16;
+                                                                int NT, Work wk, float* __restrict__ bn_partial, int MT) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NACC = TM * TN * 16;
+  __shared__ float smem[2 * WM * BN];
   const int rt = blockIdx.x, tile = wk.dp_tiles + rt;
   const int mt = tile / NT, nt = tile - mt * NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
-#pragma unroll 4
-  for (int q = 0; q < 16; ++q) {
-    const int f = blockIdx.y * 16 + q;
-    float v = 0.f;
-    for (int sl = 0; sl < wk.split; ++sl) v += slab[((size_t)(rt * wk.split + sl) * NACC + f) * 256 + tid];
-    const int e = f & 15, ij = f >> 4, i = ij / TN, j = ij - i * TN;
-    fprop_store(y, g, mt * BM + wm0 + 32 * i + acc_row(e, lane), nt * BN + wn0 + 32 * j + (lane & 31), v);
+  // all NACC loads of one slice are independent: keep them in flight together, slices summed in order
+  float v[TM * TN * 16];
+#pragma unroll
+  for (int f = 0; f < NACC; ++f) v[f] = 0.f;
+  for (int sl = 0; sl < wk.split; ++sl) {
+    const float* src = slab + (size_t)(rt * wk.split + sl) * NACC * 256 + tid;
+#pragma unroll
+    for (int f = 0; f < NACC; ++f) v[f] += src[(size_t)f * 256];
   }
+  float cs[TN], cq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) cs[j] = cq[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float val = v[(i * TN + j) * 16 + e];
+        const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
+        fprop_store(y, g, row, nt * BN + wn0 + 32 * j + (lane & 31), val);
+        if (row < g.M) {
+          cs[j] += val;
+          cq[j] += val * val;
+        }
+      }
+  if (bn_partial != nullptr) tile_colstats<BM, BN, WM, WN>(smem, cs, cq, bn_partial, MT, g.Cout, mt, nt, tid);
 }
 
 // =========================================================================================
@@ -678,7 +747,7 @@ int resident_blocks(KernelT kernel) {
 // (r < cus tiles) is cut along K into `split` slices per tile so that its blocks spread over all CUs.
 // Cost model in microseconds: one K-iteration of a 64-accumulator block = 0.85 us of one CU's MFMA pipes;
 // a CU with 1 / 2 blocks reaches ~65 % / ~85 % of that rate; the fix-up moves 2 x seg_bytes per slice, mostly
-// through the Infinity Cache (~8 TB/s).
+// through the Infinity Cache (~8 TB/s), and is latency-bound per slice.
 Work plan_work(int tiles, int nk, int W, size_t seg_bytes, size_t ws_bytes) {
   const int cus = 256;
   (void)W;
@@ -696,7 +765,8 @@ Work plan_work(int tiles, int nk, int W, size_t seg_bytes, size_t ws_bytes) {
     if (sp > 1 && need > ws_bytes) break;
     const int c = (int)(((long long)r * sp + cus - 1) / cus);
     double cost = c * ((double)nk / sp) * 0.85 / eff(c);
-    if (sp > 1) cost += 4.0 + (double)need * 2.0 / 8.0e6;
+    // fix-up launch: each thread walks the slices serially (measured ~2.5 us per slice) + launch boundary
+    if (sp > 1) cost += 10.0 + 2.5 * sp + (double)need * 2.0 / 8.0e6;
     if (cost < best * 0.95) {  // prefer fewer slices unless clearly better
       best = cost;
       best_s = sp;
@@ -831,8 +901,15 @@ extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
   return need > 16 ? need : 16;
 }
 
-extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* gg, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+extern "C" int bdv_conv_fprop_stat_rows(const bdv_conv_geom* gg) {
+  if (check_geom(gg, "bdv_conv_fprop_stat_rows")) return 0;
+  const int bm = (gg->Cout % 128) == 0 ? 128 : 256;
+  const int64_t M = (int64_t)gg->N * gg->Ho * gg->Wo;
+  return (int)((M + bm - 1) / bm);
+}
+
+extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* gg, float* bn_partial,
+                              void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_fprop")) return e;
   BDV_REQUIRE(x && w && y, "bdv_conv_fprop: null pointer");
   BDV_REQUIRE(bdv_aligned16(x) && bdv_aligned16(w) && bdv_aligned16(y) && bdv_aligned16(workspace),
@@ -851,22 +928,24 @@ extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bd
             g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.W, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
   if (p.wide) {
     if (vec_tap)
-      hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2, true>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab);
+      hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2, true>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, bn_partial, p.MT);
     else
-      hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2, false>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab);
+      hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2, false>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, bn_partial, p.MT);
   } else {
     if (vec_tap)
-      hipLaunchKernelGGL((conv_fprop_kernel<256, 64, 4, 1, true>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab);
+      hipLaunchKernelGGL((conv_fprop_kernel<256, 64, 4, 1, true>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, bn_partial, p.MT);
     else
-      hipLaunchKernelGGL((conv_fprop_kernel<256, 64, 4, 1, false>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab);
+      hipLaunchKernelGGL((conv_fprop_kernel<256, 64, 4, 1, false>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, bn_partial, p.MT);
   }
   BDV_LAUNCH_CHECK("bdv_conv_fprop");
   if (p.wk.split > 1) {
-    const dim3 fg(p.wk.rem_tiles, 4);
+    const dim3 fg(p.wk.rem_tiles);
     if (p.wide)
-      hipLaunchKernelGGL((conv_fprop_fixup_kernel<128, 128, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk);
+      hipLaunchKernelGGL((conv_fprop_fixup_kernel<128, 128, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk,
+                         bn_partial, p.MT);
     else
-      hipLaunchKernelGGL((conv_fprop_fixup_kernel<256, 64, 4, 1>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk);
+      hipLaunchKernelGGL((conv_fprop_fixup_kernel<256, 64, 4, 1>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk,
+                         bn_partial, p.MT);
     BDV_LAUNCH_CHECK("bdv_conv_fprop(fixup)");
   }
   return BDV_OK;

@@ -102,16 +102,20 @@ class UnitSpec:
         return K.make_geom(N, H, W, self.cin, self.cout, self.k, self.k, self.stride, self.pad, self.T, self.fold)
 
 
-def _bn_forward(y, bn, gamma, beta, training):
-    """-> (mean, invstd, scale, shift); running stats are updated in place when training."""
+def _conv_bn_forward(x, w_krsc, g, bn, gamma, beta, training):
+    """conv + BatchNorm statistics -> (y, mean, invstd, scale, shift).  In training the batch statistics come out of
+    the conv epilogue (no extra pass over y); running stats are updated in place."""
     if training:
         if bn.momentum is None:
             raise NotImplementedError('BatchNorm momentum=None (cumulative average) is not supported by the HIP path')
         rm = bn.running_mean if bn.track_running_stats else None
         rv = bn.running_var if bn.track_running_stats else None
-        return K.bn_train_stats(y, gamma, beta, bn.eps, bn.momentum, rm, rv)
+        y, part = K.conv_fprop(x, w_krsc, g, bn_stats=True)
+        mean, invstd, scale, shift = K.bn_train_finalize(part, g.N * g.Ho * g.Wo, gamma, beta, bn.eps, bn.momentum, rm, rv)
+        return y, mean, invstd, scale, shift
+    y = K.conv_fprop(x, w_krsc, g)
     scale, shift = K.bn_eval_params(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
-    return None, None, scale, shift
+    return y, None, None, scale, shift
 
 
 class StemFn(torch.autograd.Function):
@@ -123,8 +127,7 @@ class StemFn(torch.autograd.Function):
         g = K.make_geom(N, H, W, 4, weight.shape[0], weight.shape[2], weight.shape[3], 2, weight.shape[2] // 2)
         w4 = torch.zeros((weight.shape[0], weight.shape[2], weight.shape[3], 4), dtype=torch.float32, device=x4.device)
         w4[..., :3] = weight.detach().permute(0, 2, 3, 1)           # 37 KB repack, plumbing
-        y = K.conv_fprop(x4, w4, g)
-        mean, invstd, scale, shift = _bn_forward(y, bn, gamma, beta, training)
+        y, mean, invstd, scale, shift = _conv_bn_forward(x4, w4, g, bn, gamma, beta, training)
         save = training and any(ctx.needs_input_grad)
         if save:
             a, mask = K.bn_apply(y, scale, shift, None, True, want_mask=True)
@@ -172,8 +175,7 @@ class ResBlockFn(torch.autograd.Function):
             u = units[n_main]
             wd, gd, bd = params[3 * n_main:3 * n_main + 3]
             g = u.geom(N, H, W)
-            yd = K.conv_fprop(x, weight_krsc(wd), g)
-            mean_d, invstd_d, sc, sh = _bn_forward(yd, bns[n_main], gd, bd, training)
+            yd, mean_d, invstd_d, sc, sh = _conv_bn_forward(x, weight_krsc(wd), g, bns[n_main], gd, bd, training)
             identity = K.bn_apply(yd, sc, sh, None, False)
         else:
             identity = x
@@ -184,8 +186,7 @@ class ResBlockFn(torch.autograd.Function):
             wt, gm, bt = params[3 * i:3 * i + 3]
             g = u.geom(N, h, w_)
             geoms.append(g)
-            y = K.conv_fprop(cur, weight_krsc(wt), g)
-            mean, invstd, sc, sh = _bn_forward(y, bns[i], gm, bt, training)
+            y, mean, invstd, sc, sh = _conv_bn_forward(cur, weight_krsc(wt), g, bns[i], gm, bt, training)
             last = i == n_main - 1
             if save:
                 a, mask = K.bn_apply(y, sc, sh, identity if last else None, True, want_mask=True)

@@ -65,15 +65,23 @@ def _conv_ws(g: ConvGeom, kind: int, device, tag: str) -> torch.Tensor:
 
 
 def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torch.Tensor] = None,
-               ws_tag: str = 'conv') -> torch.Tensor:
-    """x (N,H,W,Cin) NHWC, w (Cout,R,S,Cin) -> y (N,Ho,Wo,Cout)."""
+               ws_tag: str = 'conv', bn_stats: bool = False):
+    """x (N,H,W,Cin) NHWC, w (Cout,R,S,Cin) -> y (N,Ho,Wo,Cout); with bn_stats also the fused BatchNorm partial
+    sums (float[2][rows][Cout]) for ``bn_train_finalize``."""
     _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
     _chk(w, (g.Cout, g.R, g.S, g.Cin), name='w')
     y = out if out is not None else torch.empty((g.N, g.Ho, g.Wo, g.Cout), dtype=torch.float32, device=x.device)
     _chk(y, (g.N, g.Ho, g.Wo, g.Cout), name='y')
     ws = _conv_ws(g, 0, x.device, ws_tag)
-    check(lib().bdv_conv_fprop(_p(x), _p(w), _p(y), ctypes.byref(g), _p(ws), ws.numel(), _stream()), 'bdv_conv_fprop')
-    return y
+    part = None
+    if bn_stats:
+        rows = lib().bdv_conv_fprop_stat_rows(ctypes.byref(g))
+        if rows <= 0:
+            check(-1, 'bdv_conv_fprop_stat_rows')
+        part = torch.empty((2, rows, g.Cout), dtype=torch.float32, device=x.device)
+    check(lib().bdv_conv_fprop(_p(x), _p(w), _p(y), ctypes.byref(g), _p(part), _p(ws), ws.numel(), _stream()),
+          'bdv_conv_fprop')
+    return (y, part) if bn_stats else y
 
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional[torch.Tensor] = None,
@@ -132,6 +140,22 @@ def bn_train_stats(y, gamma, beta, eps, momentum, running_mean, running_var):
     check(lib().bdv_bn_train_stats(_p(y), M, C, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
                                    _p(running_var), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), _p(ws),
                                    ws.numel(), _stream()), 'bdv_bn_train_stats')
+    return stats[0], stats[1], stats[2], stats[3]
+
+
+def bn_train_finalize(partial, M, gamma, beta, eps, momentum, running_mean, running_var):
+    """partial float[2][rows][C] from conv_fprop(bn_stats=True) -> (save_mean, save_invstd, scale, shift)."""
+    _chk(partial, name='partial')
+    _, rows, C = partial.shape
+    for t, n in ((gamma, 'gamma'), (beta, 'beta')):
+        _chk(t, (C,), name=n)
+    if running_mean is not None:
+        _chk(running_mean, (C,), name='running_mean')
+        _chk(running_var, (C,), name='running_var')
+    stats = torch.empty((4, C), dtype=torch.float32, device=partial.device)
+    check(lib().bdv_bn_train_finalize(_p(partial), rows, int(M), C, _p(gamma), _p(beta), float(eps), float(momentum),
+                                      _p(running_mean), _p(running_var), _p(stats[0]), _p(stats[1]), _p(stats[2]),
+                                      _p(stats[3]), _stream()), 'bdv_bn_train_finalize')
     return stats[0], stats[1], stats[2], stats[3]
 
 

@@ -57,7 +57,11 @@ int bdv_abi_version(void);
  * for the K-split partial accumulators of the remainder tiles (tile counts that do not fill whole rounds of
  * co-resident workgroups on the 256 CUs); passing NULL disables the split (correct, slower on such shapes). */
 size_t bdv_conv_workspace_bytes(const bdv_conv_geom* g, int kind);
-int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* g, void* workspace,
+/* bn_partial (optional): float[2][rows][Cout], rows = bdv_conv_fprop_stat_rows(g).  When given, the epilogue also
+ * writes per-row-tile column sums of y and y*y (the BatchNorm batch statistics, fused: y is not re-read);
+ * bdv_bn_train_finalize reduces them in fixed order. */
+int bdv_conv_fprop_stat_rows(const bdv_conv_geom* g);
+int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* g, float* bn_partial, void* workspace,
                    size_t workspace_bytes, void* stream);
 
 /* dgrad: dx[N,H,W,Cin] = unshift(conv_transpose(dy, w)) + (add_src ? add_src * mask : 0),
@@ -84,6 +88,10 @@ int bdv_bn_train_stats(const float* y, int64_t M, int C, const float* gamma, con
                        float eps, float momentum, float* running_mean, float* running_var,
                        float* save_mean, float* save_invstd, float* scale, float* shift,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* same outputs as bdv_bn_train_stats, from the partial sums written by bdv_conv_fprop(bn_partial) */
+int bdv_bn_train_finalize(const float* partial, int rows, int64_t M, int C, const float* gamma, const float* beta,
+                          float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                          float* save_invstd, float* scale, float* shift, void* stream);
 /* eval: scale/shift from running statistics. */
 int bdv_bn_eval_params(int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, void* stream);

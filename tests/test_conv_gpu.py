@@ -142,3 +142,34 @@ def test_bad_shapes_raise(dev):
     bad = K.make_geom(2, 8, 8, 64, 96, 3, 3, 1, 1)        # Cout not a multiple of 64
     with pytest.raises(HipExtensionError):
         K.conv_fprop(x, torch.zeros(96, 3, 3, 64, device=dev), bad)
+
+
+@pytest.mark.parametrize('shape', [(8, 14, 14, 64, 128, 1), (64, 14, 14, 256, 256, 3), (32, 28, 28, 64, 64, 3), (3, 18, 22, 4, 64, 7)])
+def test_fused_bn_statistics(shape, dev):
+    """BatchNorm batch statistics from the fprop epilogue (incl. K-split remainder tiles -> fix-up kernel) equal the
+    column sums of the stored y, and bn_train_finalize equals torch's batch_norm statistics."""
+    from bdvcil_amd import kernels as K
+    N, H, W, Cin, Cout, R = shape
+    st, pad = (2, 3) if R == 7 else (1, R // 2)
+    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad)
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randn(N, H, W, Cin, generator=gen) + 0.3).to(dev)
+    w = (torch.randn(Cout, R, R, Cin, generator=gen) / (Cin * R * R) ** 0.5).to(dev)
+    y_plain = K.conv_fprop(x, w, g)
+    y, part = K.conv_fprop(x, w, g, bn_stats=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_plain)
+    yc = y.reshape(-1, Cout).double().cpu()
+    M = yc.shape[0]
+    s1, s2 = part[0].double().sum(0).cpu(), part[1].double().sum(0).cpu()
+    assert (s1 - yc.sum(0)).abs().max() <= 1e-5 * yc.abs().sum(0).max()
+    assert (s2 - (yc * yc).sum(0)).abs().max() <= 1e-5 * (yc * yc).sum(0).max()
+    gamma, beta = torch.rand(Cout, generator=gen) + 0.5, torch.randn(Cout, generator=gen)
+    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    mean, invstd, scale, shift = K.bn_train_finalize(part, M, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rmd, rvd)
+    ref_mean, ref_var = yc.mean(0), yc.var(0, unbiased=False)
+    assert (mean.cpu().double() - ref_mean).abs().max() <= 1e-5 * (ref_mean.abs().max() + 1)
+    assert ((invstd.cpu().double() - 1 / (ref_var + 1e-5).sqrt()).abs() * (ref_var + 1e-5).sqrt()).max() <= 1e-4
+    assert (rmd.cpu().double() - 0.1 * ref_mean).abs().max() <= 1e-5
+    assert (rvd.cpu().double() - (0.9 + 0.1 * yc.var(0, unbiased=True))).abs().max() <= 1e-4
