@@ -4,22 +4,53 @@
 // Replaces: F.conv2d + autograd inside UPSTREAM mmaction ConvModule, and UPSTREAM
 // TemporalShift.shift (fused into the activation-tile gather).
 //
-// Structure of every kernel: 256 threads = 4 waves; block tile BM x BN, K-step 16;
-// LDS image of both operands is k-major ([k][m], row stride BM+4 floats) so one MFMA operand
-// is one conflict-free ds_read_b32 (lane l reads [k = 2s + l/32][m = base + l%32]);
-// register-staged global->LDS double buffering with one barrier per K-step.
+// Structure of every kernel (chosen with tools/ubench/gemm_variants.hip: 124-130 TFLOP/s at any grid size,
+// vs 97-122 for a 16-deep double-buffered loop):
+//   * 256 threads = 4 waves; block tile BM x BN; K-step 32; wave tile = 2x2 / 2x1 MFMA 32x32 tiles;
+//   * ONE LDS stage: K-major image ([k][m]) of both operands, so one MFMA operand is one conflict-free
+//     ds_read_b32 (lane l reads [k = 2s + l/32][m = base + l%32]); operand fragments are fetched one K-pair
+//     ahead of the MFMAs (order pinned with sched_group_barrier);
+//   * register-staged global loads, issued right after the stage is published and consumed after the MFMAs:
+//     barrier, store registers -> LDS, barrier, issue next loads, 64 MFMAs;
+//   * K-contiguous operands are read as full 128-byte lines (8 lanes x 16 B per row) and stored transposed
+//     (row stride BM+1: the 8x4 lane pattern hits 32 distinct banks); M-contiguous operands are stored with
+//     16-byte writes (row stride BM+4);
+//   * halo / clip-end / ragged lanes use buffer loads with an out-of-range offset (hardware returns zeros).
 #include <stdlib.h>
 #include "common.h"
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 
 struct Geom {
   int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, T, fold;
   int M;     // GEMM rows: N*Ho*Wo (fprop / wgrad reduction length), N*H*W (dgrad)
   int Ktot;  // fprop: R*S*Cin ; dgrad: R*S*Cout ; wgrad: row length of dw = R*S*Cin
+  float rcp_HoWo, rcp_Wo;  // fast division helpers (dividends < 2^22)
 };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kOOB = (int)0x80000000;  // byte offset beyond any tensor (< 2^31 bytes checked on the host)
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// q = m / d, r = m % d for 0 <= m < 2^22 with a float reciprocal and one correction step each way
+__device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int& r) {
+  q = (int)((float)m * rcp);
+  r = m - q * d;
+  if (r < 0) {
+    r += d;
+    --q;
+  }
+  if (r >= d) {
+    r -= d;
+    ++q;
+  }
+}
 
 template <int LDA, int LDB, int TM, int TN>
 __device__ __forceinline__ void mma_stage(const float* __restrict__ As, const float* __restrict__ Bs,
@@ -27,7 +58,7 @@ __device__ __forceinline__ void mma_stage(const float* __restrict__ As, const fl
   const int r = lane & 31, h = lane >> 5;
   const float* ap = As + h * LDA + wm0 + r;
   const float* bp = Bs + h * LDB + wn0 + r;
-  // operand fragments are fetched one K-step ahead of the MFMAs that consume them
+  // operand fragments are fetched one K-pair ahead of the MFMAs that consume them
   float a[2][TM], b[2][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) a[0][i] = ap[32 * i];
@@ -48,7 +79,7 @@ __device__ __forceinline__ void mma_stage(const float* __restrict__ As, const fl
       for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
     // pin the order: next step's LDS reads first, then this step's MFMAs (hipcc otherwise sinks the reads
-    // to just before their use and exposes the LDS latency every K-step)
+    // to just before their use and exposes the LDS latency every K-pair)
     __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
   }
@@ -59,13 +90,13 @@ __device__ __forceinline__ int shift_class(int c, int fold) {
   return (fold > 0) ? (c < fold ? 1 : (c < 2 * fold ? -1 : 0)) : 0;
 }
 
-// K-contiguous source tile (rows x 16 k) -> transposing store into the k-major LDS image.
+// K-contiguous source tile (ROWS x 32 k, thread = (row tid/8, 16-byte group tid%8)) -> transposing store
 template <int LD, int PASSES>
 __device__ __forceinline__ void store_transposed(float* __restrict__ dst, const float4 (&v)[PASSES], int tid) {
-  const int row = tid >> 2, kg = tid & 3;
+  const int row = tid >> 3, kg = tid & 7;
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
-    float* d = dst + (4 * kg) * LD + row + 64 * p;
+    float* d = dst + (4 * kg) * LD + row + 32 * p;
     d[0] = v[p].x;
     d[LD] = v[p].y;
     d[2 * LD] = v[p].z;
@@ -73,7 +104,7 @@ __device__ __forceinline__ void store_transposed(float* __restrict__ dst, const 
   }
 }
 
-// M-contiguous source tile (16 k rows x COLS) -> direct 16-byte stores.
+// M-contiguous source tile (32 k rows x COLS) -> direct 16-byte stores
 template <int LD, int COLS, int PASSES>
 __device__ __forceinline__ void store_direct(float* __restrict__ dst, const float4 (&v)[PASSES], int tid) {
   constexpr int V = COLS / 4;
@@ -90,9 +121,8 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // ---- work decomposition -------------------------------------------------------------------
 // A launch covers `dp_tiles` whole output tiles (one block each, XCD-aware order) followed by `rem_tiles` tiles
 // whose K loop is cut into `split` slices (one block per slice, partial accumulators to a slab, summed in fixed
-// order by a fix-up kernel).  The host planner picks (dp_tiles, split) so that the block count is a multiple of
-// the number of co-resident blocks: on 256 CUs a tile count just above a multiple otherwise costs a whole extra
-// round (measured: 784 tiles -> 82 TFLOP/s, 768 or 1024 tiles -> 113-120).
+// order by a fix-up kernel).  The host planner picks (dp_tiles, split) so that the last, partial round of
+// co-resident blocks consists of many short blocks (measured: 784 tiles -> 82 TFLOP/s, 768 -> 113).
 struct Work {
   int dp_tiles, rem_tiles, split;
 };
@@ -136,11 +166,21 @@ __device__ __forceinline__ void store_partial(float* __restrict__ slab, int pslo
       for (int e = 0; e < 16; ++e) base[(size_t)((i * TN + j) * 16 + e) * 256] = acc[i][j][e];
 }
 
+template <int TM, int TN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+}
+
 __device__ __forceinline__ void fprop_store(float* __restrict__ y, const Geom& g, int row, int col, float v) {
   if (row < g.M) y[(size_t)row * g.Cout + col] = v;
 }
 
-// dgrad element store for stride 1: temporal un-shift scatter + optional masked residual add (see kernel comment)
+// dgrad element store: temporal un-shift scatter + optional masked residual add (see kernel comment)
 __device__ __forceinline__ void dgrad_store(float* __restrict__ dx, const float* __restrict__ add_src,
                                             const uint32_t* __restrict__ add_mask, const Geom& g, int HW, int row, int n_hint,
                                             bool have_n, int col, float v) {
@@ -179,7 +219,7 @@ __device__ __forceinline__ void tile_colstats(float* __restrict__ smem, float (&
     cs[j] += __shfl_xor(cs[j], 32, 64);
     cq[j] += __shfl_xor(cq[j], 32, 64);
   }
-  __syncthreads();  // every wave is done with the operand stages in LDS
+  __syncthreads();  // every wave is done with the operand stage in LDS
   if (lane < 32) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -200,112 +240,13 @@ __device__ __forceinline__ void tile_colstats(float* __restrict__ smem, float (&
   }
 }
 
-// =========================================================================================
-// fprop: y[m, co] = sum_{tap, ci} x_shift[n, ho*st + r - p, wo*st + s - p, ci] * w[co, tap, ci]
-// =========================================================================================
-template <int BM, int BN, int WM, int WN, bool VEC_TAP>
-__global__ __launch_bounds__(256) void conv_fprop_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          float* __restrict__ y, Geom g, int NT, Work wk,
-                                                          float* __restrict__ slab, float* __restrict__ bn_partial, int MT) {
-  constexpr int LDA = BM + 4, LDB = BN + 4;
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void fprop_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ smem,
+                                               float* __restrict__ y, const Geom& g, float* __restrict__ bn_partial, int MT,
+                                               int mt, int nt, int tid) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int AP = BM / 64, BP = BN / 64;
-  constexpr int STAGE = BK * (LDA + LDB);
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
-
-  // Tile order: Cout-tile fastest, so the blocks that share an activation row-tile are consecutive and
-  // (through xcd_remap) land on one XCD / one L2.
-  const int nk = (g.Ktot + BK - 1) / BK;
-  const WorkItem it = get_work(blockIdx.x, wk, nk);
-  const int mt = it.tile / NT, nt = it.tile - mt * NT;
-
-  const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
-  const int arow = tid >> 2, kg = tid & 3;
-  const int HoWo = g.Ho * g.Wo;
-
-  int a_n[AP], a_t[AP], a_hi0[AP], a_wi0[AP];
-  bool a_ok[AP];
-#pragma unroll
-  for (int p = 0; p < AP; ++p) {
-    const int m = mt * BM + arow + 64 * p;
-    a_ok[p] = m < g.M;
-    const int mm = a_ok[p] ? m : 0;
-    const int n = mm / HoWo;
-    const int rem = mm - n * HoWo;
-    const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
-    a_n[p] = n;
-    a_t[p] = n % g.T;
-    a_hi0[p] = ho * g.stride - g.pad;
-    a_wi0[p] = wo * g.stride - g.pad;
-  }
-  const int RS = g.R * g.S;
-
-  float4 ra[AP], rb[BP];
-  auto load = [&](int kt) {
-    int tap, c;
-    if (VEC_TAP) {
-      const int k = kt * BK + 4 * kg;
-      tap = k / g.Cin;
-      c = k - tap * g.Cin;
-    } else {
-      // tap-fastest K order: the R*S taps of one 16-channel chunk are consecutive K-steps, so the shifted
-      // re-reads of the same activation rows hit L1/L2 instead of going back to the fabric R*S times.
-      const int chunk = kt / RS;
-      tap = kt - chunk * RS;
-      c = chunk * BK + 4 * kg;
-    }
-    const int r = tap / g.S, s = tap - r * g.S;
-    const bool kvalid = tap < RS;
-    const int cls = shift_class(c, g.fold);
-#pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      const int hi = a_hi0[p] + r, wi = a_wi0[p] + s;
-      const bool v = a_ok[p] && kvalid && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W &&
-                     (unsigned)(a_t[p] + cls) < (unsigned)g.T;
-      const size_t off = ((size_t)((a_n[p] + cls) * g.H + hi) * g.W + wi) * g.Cin + c;
-      ra[p] = v ? *reinterpret_cast<const float4*>(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const int kb = VEC_TAP ? kt * BK + 4 * kg : tap * g.Cin + c;
-#pragma unroll
-    for (int p = 0; p < BP; ++p) {
-      const int co = nt * BN + arow + 64 * p;
-      rb[p] = (kb < g.Ktot) ? *reinterpret_cast<const float4*>(w + (size_t)co * g.Ktot + kb)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto store = [&](int buf) {
-    float* As = smem + buf * STAGE;
-    float* Bs = As + BK * LDA;
-    store_transposed<LDA, AP>(As, ra, tid);
-    store_transposed<LDB, BP>(Bs, rb, tid);
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  load(it.kb);
-  store(0);
-  __syncthreads();
-  for (int kt = it.kb; kt < it.ke; ++kt) {
-    const int cur = (kt - it.kb) & 1;
-    if (kt + 1 < it.ke) load(kt + 1);
-    const float* As = smem + cur * STAGE;
-    mma_stage<LDA, LDB, TM, TN>(As, As + BK * LDA, acc, wm0, wn0, lane);
-    if (kt + 1 < it.ke) store(cur ^ 1);
-    __syncthreads();
-  }
-
-  if (it.pslot >= 0) {
-    store_partial<TM, TN>(slab, it.pslot, acc, tid);
-    return;
-  }
   float cs[TN], cq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) cs[j] = cq[j] = 0.f;
@@ -325,8 +266,173 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const float* __restrict
         }
       }
     }
-  if (bn_partial != nullptr)
-    tile_colstats<BM, BN, WM, WN>(smem, cs, cq, bn_partial, MT, g.Cout, mt, nt, tid);
+  if (bn_partial != nullptr) tile_colstats<BM, BN, WM, WN>(smem, cs, cq, bn_partial, MT, g.Cout, mt, nt, tid);
+}
+
+// =========================================================================================
+// fprop: y[m, co] = sum_{tap, ci} x_shift[n, ho*st + r - p, wo*st + s - p, ci] * w[co, tap, ci]
+// K order is tap-fastest: the R*S taps of one 32-channel chunk are consecutive K-steps, so the shifted re-reads of
+// the same activation rows hit L1/L2 instead of going back to the fabric R*S times.
+// =========================================================================================
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 3) void conv_fprop_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ y, Geom g, int NT, Work wk,
+                                                          float* __restrict__ slab, float* __restrict__ bn_partial, int MT) {
+  constexpr int LDA = BM + 1, LDB = BN + 1;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AP = BM / 32, BP = BN / 32;
+  __shared__ __attribute__((aligned(16))) float smem[BK * (LDA + LDB)];
+  float* const As = smem;
+  float* const Bs = smem + BK * LDA;
+
+  // Tile order: Cout-tile fastest, so the blocks that share an activation row-tile are consecutive and
+  // (through xcd_remap) land on one XCD / one L2.
+  const int nk = g.Ktot / BK;
+  const WorkItem it = get_work(blockIdx.x, wk, nk);
+  const int mt = it.tile / NT, nt = it.tile - mt * NT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int arow = tid >> 3, kg = tid & 7;
+  const int HoWo = g.Ho * g.Wo;
+  const int frame_bytes = g.H * g.W * g.Cin * 4;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * frame_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, g.Cout * g.Ktot * 4, 0x00020000);
+
+  int a_base[AP], a_t[AP], a_hi0[AP], a_wi0[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int m = mt * BM + arow + 32 * p;
+    const bool ok = m < g.M;
+    int n, rem, ho, wo;
+    fast_divmod(ok ? m : 0, HoWo, g.rcp_HoWo, n, rem);
+    fast_divmod(rem, g.Wo, g.rcp_Wo, ho, wo);
+    a_t[p] = n % g.T;
+    a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);  // rows past M fail every bounds test
+    a_wi0[p] = wo * g.stride - g.pad;
+    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad) * g.Cin * 4 + 16 * kg;
+  }
+  int b_base[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) b_base[p] = ((nt * BN + arow + 32 * p) * g.Ktot + 4 * kg) * 4;
+
+  // K index state (uniform): K-step kt = chunk * R*S + r * S + s
+  const int RS = g.R * g.S;
+  int chunk = it.kb / RS, r, s;
+  {
+    const int tap = it.kb - chunk * RS;
+    r = tap / g.S;
+    s = tap - r * g.S;
+  }
+
+  float4 ra[AP], rb[BP];
+  auto load = [&]() {
+    const int cls = shift_class(chunk * BK + 4 * kg, g.fold);
+    const int koff_a = ((r * g.W + s) * g.Cin + chunk * BK) * 4;
+    const int koff_b = ((r * g.S + s) * g.Cin + chunk * BK) * 4;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const bool v = (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W &&
+                     (unsigned)(a_t[p] + cls) < (unsigned)g.T;
+      // invalid lanes: set the top bit -> beyond num_records -> the load returns zeros
+      ra[p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB), 0);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p) rb[p] = buf_load16(wr, b_base[p], koff_b);
+    // advance to the next K-step (branch-free)
+    s += 1;
+    const int ws_ = (s == g.S) ? 1 : 0;
+    s = ws_ ? 0 : s;
+    r += ws_;
+    const int wr_ = (r == g.R) ? 1 : 0;
+    r = wr_ ? 0 : r;
+    chunk += wr_;
+  };
+
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+
+  load();
+  for (int kt = it.kb; kt < it.ke; ++kt) {
+    __syncthreads();  // everyone is done reading the previous stage
+    store_transposed<LDA, AP>(As, ra, tid);
+    store_transposed<LDB, BP>(Bs, rb, tid);
+    __syncthreads();
+    if (kt + 1 < it.ke) load();  // in flight during the MFMAs
+    mma_stage<LDA, LDB, TM, TN>(As, Bs, acc, wm0, wn0, lane);
+  }
+
+  if (it.pslot >= 0) {
+    store_partial<TM, TN>(slab, it.pslot, acc, tid);
+    return;
+  }
+  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, bn_partial, MT, mt, nt, tid);
+}
+
+// fprop for the stem (Cin = 4 on NHWC4): one filter tap per 16-byte load, K = R*S*4 padded to a multiple of 32
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             float* __restrict__ y, Geom g, int NT, float* __restrict__ bn_partial,
+                                                             int MT) {
+  constexpr int LDA = BM + 1, LDB = BN + 1;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AP = BM / 32, BP = BN / 32;
+  __shared__ __attribute__((aligned(16))) float smem[BK * (LDA + LDB)];
+  float* const As = smem;
+  float* const Bs = smem + BK * LDA;
+  const int tile = xcd_remap(blockIdx.x, MT * NT);
+  const int mt = tile / NT, nt = tile - mt * NT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int arow = tid >> 3, kg = tid & 7;
+  const int HoWo = g.Ho * g.Wo;
+  const int RS = g.R * g.S;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * g.H * g.W * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, g.Cout * g.Ktot * 4, 0x00020000);
+
+  int a_base[AP], a_hi0[AP], a_wi0[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int m = mt * BM + arow + 32 * p;
+    const bool ok = m < g.M;
+    const int mm = ok ? m : 0;  // up to 2^23 output pixels here: exact integer division
+    const int n = mm / HoWo;
+    const int rem = mm - n * HoWo;
+    const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+    a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);
+    a_wi0[p] = wo * g.stride - g.pad;
+    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad) * 16;
+  }
+  float4 ra[AP], rb[BP];
+  auto load = [&](int kt) {
+    const int tap = kt * (BK / 4) + kg;  // this thread's filter tap
+    const int r = tap / g.S, s = tap - r * g.S;
+    const bool kv = tap < RS;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const bool v = kv && (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W;
+      ra[p] = buf_load16(xr, (a_base[p] + (r * g.W + s) * 16) | (v ? 0 : kOOB), 0);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p)
+      rb[p] = buf_load16(wr, (((nt * BN + arow + 32 * p) * g.Ktot + tap * 4) * 4) | (kv ? 0 : kOOB), 0);
+  };
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  const int nk = (g.Ktot + BK - 1) / BK;
+  load(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    store_transposed<LDA, AP>(As, ra, tid);
+    store_transposed<LDB, BP>(Bs, rb, tid);
+    __syncthreads();
+    if (kt + 1 < nk) load(kt + 1);
+    mma_stage<LDA, LDB, TM, TN>(As, Bs, acc, wm0, wn0, lane);
+  }
+  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, bn_partial, MT, mt, nt, tid);
 }
 
 // fix-up for the K-split remainder tiles: sum the `split` partial accumulators in slice order, then the same
@@ -340,35 +446,20 @@ __global__ __launch_bounds__(256) void conv_fprop_fixup_kernel(const float* __re
   __shared__ float smem[2 * WM * BN];
   const int rt = blockIdx.x, tile = wk.dp_tiles + rt;
   const int mt = tile / NT, nt = tile - mt * NT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int tid = threadIdx.x;
   // all NACC loads of one slice are independent: keep them in flight together, slices summed in order
-  float v[TM * TN * 16];
-#pragma unroll
-  for (int f = 0; f < NACC; ++f) v[f] = 0.f;
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
   for (int sl = 0; sl < wk.split; ++sl) {
     const float* src = slab + (size_t)(rt * wk.split + sl) * NACC * 256 + tid;
 #pragma unroll
-    for (int f = 0; f < NACC; ++f) v[f] += src[(size_t)f * 256];
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += src[(size_t)((i * TN + j) * 16 + e) * 256];
   }
-  float cs[TN], cq[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) cs[j] = cq[j] = 0.f;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float val = v[(i * TN + j) * 16 + e];
-        const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
-        fprop_store(y, g, row, nt * BN + wn0 + 32 * j + (lane & 31), val);
-        if (row < g.M) {
-          cs[j] += val;
-          cq[j] += val * val;
-        }
-      }
-  if (bn_partial != nullptr) tile_colstats<BM, BN, WM, WN>(smem, cs, cq, bn_partial, MT, g.Cout, mt, nt, tid);
+  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, bn_partial, MT, mt, nt, tid);
 }
 
 // =========================================================================================
@@ -378,16 +469,18 @@ __global__ __launch_bounds__(256) void conv_fprop_fixup_kernel(const float* __re
 // epilogue: temporal un-shift (scatter to frame t+/-1) + optional masked residual-gradient add.
 // =========================================================================================
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                           float* __restrict__ dx, const float* __restrict__ add_src,
                                                           const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk,
                                                           float* __restrict__ slab) {
-  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int LDA = BM + 1, LDB = BN + 4;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int AP = BM / 64, BP = BN / 64;
+  constexpr int AP = BM / 32, BP = BN / 32;
   constexpr int BV = BN / 4;
-  constexpr int STAGE = BK * (LDA + LDB);
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  constexpr int AOFF = (BK * LDA + 3) & ~3;  // keep the B image 16-byte aligned
+  __shared__ __attribute__((aligned(16))) float smem[AOFF + BK * LDB];
+  float* const As = smem;
+  float* const Bs = smem + AOFF;
 
   // parity class of the input pixel (stride 1: a single class)
   const int st = g.stride;
@@ -399,8 +492,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict
   const int nr = r0 < g.R ? (g.R - r0 + st - 1) / st : 0;
   const int ns = s0 < g.S ? (g.S - s0 + st - 1) / st : 0;
   const int bh = (ph + g.pad - r0) / st, bw = (pw + g.pad - s0) / st;
+  const int ntap = nr * ns;
+  const int nk = ntap * g.Cout / BK;  // 0 for a class no filter tap reaches (e.g. 1x1 stride 2, odd pixels)
 
-  const int nk = nr * ns * g.Cout / BK;     // 0 for a class no filter tap reaches (e.g. 1x1 stride 2, odd pixels)
   int mt, nt;
   WorkItem it;
   if (st == 1) {
@@ -413,81 +507,84 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(const float* __restrict
     mt = (jj / NT) * 8 + xcd;
     nt = jj % NT;
     if (mt >= MT) return;
-    it.tile = 0; it.kb = 0; it.ke = nk; it.pslot = -1;
+    it.tile = 0;
+    it.kb = 0;
+    it.ke = nk;
+    it.pslot = -1;
   }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
-  const int arow = tid >> 2, kg = tid & 3;
+  const int arow = tid >> 3, kg = tid & 7;
   const int HcWc = Hc * Wc;
   const int HW = g.H * g.W;
   const int RS = g.R * g.S;
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.N * g.Ho * g.Wo * g.Cout * 4, 0x00020000);
 
-  int a_n[AP], a_h[AP], a_w[AP];
-  bool a_ok[AP];
+  int a_base[AP], a_h[AP], a_w[AP];
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
-    const int m = mt * BM + arow + 64 * p;
-    a_ok[p] = m < Mc;
-    const int mm = a_ok[p] ? m : 0;
+    const int m = mt * BM + arow + 32 * p;
+    const bool ok = m < Mc;
+    const int mm = ok ? m : 0;
     const int n = mm / HcWc;
     const int rem = mm - n * HcWc;
-    const int hc = rem / Wc;
-    a_n[p] = n;
-    a_h[p] = hc + bh;
-    a_w[p] = rem - hc * Wc + bw;
+    const int hc = rem / Wc, wc = rem - hc * Wc;
+    a_h[p] = ok ? hc + bh : -(1 << 20);
+    a_w[p] = wc + bw;
+    a_base[p] = ((n * g.Ho + hc + bh) * g.Wo + wc + bw) * g.Cout * 4 + 16 * kg;
+  }
+  // weights: tile [32 co rows][BN ci] of tap `tap`: element ((co0 + krow) * RS + tap) * Cin + nt*BN + 4*c4
+  int b_base[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) {
+    const int idx = tid + 256 * p;
+    const int krow = idx / BV, c4 = idx - krow * BV;
+    b_base[p] = krow * RS * g.Cin + nt * BN + 4 * c4;
+  }
+
+  // K index state (uniform): kt = chunk * ntap + ir * ns + is  (tap-fastest)
+  int chunk = ntap > 0 ? it.kb / ntap : 0, ir, is;
+  {
+    const int ct = ntap > 0 ? it.kb - chunk * ntap : 0;
+    ir = ns > 0 ? ct / ns : 0;
+    is = ct - ir * ns;
   }
 
   float4 ra[AP], rb[BP];
-  auto load = [&](int kt) {
-    const int ntap = nr * ns;               // tap-fastest K order (see fprop)
-    const int chunk = kt / ntap;
-    const int ct = kt - chunk * ntap;       // tap index inside this class
-    const int co0 = chunk * BK;
-    const int ir = ct / ns, is = ct - ir * ns;
+  auto load = [&]() {
     const int tap = (r0 + ir * st) * g.S + (s0 + is * st);
+    const int koff_a = (chunk * BK - (ir * g.Wo + is) * g.Cout) * 4;
+    const int koff_b = (chunk * BK * RS + tap) * g.Cin;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const int ho = a_h[p] - ir, wo = a_w[p] - is;
-      const bool v = a_ok[p] && (unsigned)ho < (unsigned)g.Ho && (unsigned)wo < (unsigned)g.Wo;
-      const size_t off = ((size_t)(a_n[p] * g.Ho + ho) * g.Wo + wo) * g.Cout + co0 + 4 * kg;
-      ra[p] = v ? *reinterpret_cast<const float4*>(dy + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool v = (unsigned)(a_h[p] - ir) < (unsigned)g.Ho && (unsigned)(a_w[p] - is) < (unsigned)g.Wo;
+      ra[p] = buf_load16(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB), 0);
     }
 #pragma unroll
-    for (int p = 0; p < BP; ++p) {
-      const int idx = tid + 256 * p;
-      const int krow = idx / BV, c4 = idx - krow * BV;
-      const size_t off = ((size_t)(co0 + krow) * RS + tap) * g.Cin + nt * BN + 4 * c4;
-      rb[p] = *reinterpret_cast<const float4*>(w + off);
-    }
-  };
-  auto store = [&](int buf) {
-    float* As = smem + buf * STAGE;
-    float* Bs = As + BK * LDA;
-    store_transposed<LDA, AP>(As, ra, tid);
-    store_direct<LDB, BN, BP>(Bs, rb, tid);
+    for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const float4*>(w + (size_t)(b_base[p] + koff_b));
+    is += 1;
+    const int w1 = (is == ns) ? 1 : 0;
+    is = w1 ? 0 : is;
+    ir += w1;
+    const int w2 = (ir == nr) ? 1 : 0;
+    ir = w2 ? 0 : ir;
+    chunk += w2;
   };
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  zero_acc<TM, TN>(acc);
 
   if (it.ke > it.kb) {
-    load(it.kb);
-    store(0);
-    __syncthreads();
+    load();
     for (int kt = it.kb; kt < it.ke; ++kt) {
-      const int cur = (kt - it.kb) & 1;
-      if (kt + 1 < it.ke) load(kt + 1);
-      const float* As = smem + cur * STAGE;
-      mma_stage<LDA, LDB, TM, TN>(As, As + BK * LDA, acc, wm0, wn0, lane);
-      if (kt + 1 < it.ke) store(cur ^ 1);
       __syncthreads();
+      store_transposed<LDA, AP>(As, ra, tid);
+      store_direct<LDB, BN, BP>(Bs, rb, tid);
+      __syncthreads();
+      if (kt + 1 < it.ke) load();
+      mma_stage<LDA, LDB, TM, TN>(As, Bs, acc, wm0, wn0, lane);
     }
   }
   if (it.pslot >= 0) {
@@ -522,37 +619,51 @@ template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_dgrad_fixup_kernel(const float* __restrict__ slab, float* __restrict__ dx,
                                                                 const float* __restrict__ add_src,
                                                                 const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk) {
-  constexpr int TN = BN / WN / 32;
-  constexpr int NACC = (BM / WM / 32) * TN * 16;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NACC = TM * TN * 16;
   const int rt = blockIdx.x, tile = wk.dp_tiles + rt;
   const int mt = tile / NT, nt = tile - mt * NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
   const int HW = g.H * g.W;
-#pragma unroll 4
-  for (int q = 0; q < 16; ++q) {
-    const int f = blockIdx.y * 16 + q;
-    float v = 0.f;
-    for (int sl = 0; sl < wk.split; ++sl) v += slab[((size_t)(rt * wk.split + sl) * NACC + f) * 256 + tid];
-    const int e = f & 15, ij = f >> 4, i = ij / TN, j = ij - i * TN;
-    const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
-    if (row < g.M) dgrad_store(dx, add_src, add_mask, g, HW, row, 0, false, nt * BN + wn0 + 32 * j + (lane & 31), v);
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  for (int sl = 0; sl < wk.split; ++sl) {
+    const float* src = slab + (size_t)(rt * wk.split + sl) * NACC * 256 + tid;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += src[(size_t)((i * TN + j) * 16 + e) * 256];
   }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
+      if (row >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        dgrad_store(dx, add_src, add_mask, g, HW, row, 0, false, nt * BN + wn0 + 32 * j + (lane & 31), acc[i][j][e]);
+    }
 }
 
 // =========================================================================================
 // wgrad: slab[split][co][tap*Cin + ci] = sum_{m in split} dy[m, co] * x_shift[pix(m, tap), ci]
+// Both operands are M-contiguous (16-byte direct LDS stores).  C4 = stem (Cin = 4, one tap per 16-byte load).
 // =========================================================================================
-template <int BM, int BN, int WM, int WN, bool VEC_TAP>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int BM, int BN, int WM, int WN, bool C4>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           float* __restrict__ slab, Geom g, int MTw, int NTw,
                                                           int kt_per_split) {
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int AP = BM / 64, BP = BN / 64;
+  constexpr int AP = BM / 32, BP = BN / 32;
   constexpr int AV = BM / 4, BV = BN / 4;
-  constexpr int STAGE = BK * (LDA + LDB);
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) float smem[BK * (LDA + LDB)];
+  float* const As = smem;
+  float* const Bs = smem + BK * LDA;
 
   const int mt = blockIdx.x % MTw, nt = blockIdx.x / MTw;
   const int split = blockIdx.y;
@@ -560,27 +671,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   const int lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
   const int HoWo = g.Ho * g.Wo;
-  const int RS = g.R * g.S;
+  const int frame_bytes = g.H * g.W * g.Cin * 4;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * frame_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.M * g.Cout * 4, 0x00020000);
 
-  // column -> (tap, ci) for this thread's B loads (fixed over the K loop)
-  int b_tap[BP], b_ci[BP], b_krow[BP];
+  // A: dy rows m0 + krow, columns mt*BM + 4*c4
+  int a_off[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int idx = tid + 256 * p;
+    const int krow = idx / AV, c4 = idx - krow * AV;
+    a_off[p] = (krow * g.Cout + mt * BM + 4 * c4) * 4;
+  }
+  // B: column -> (tap, ci) for this thread's loads (fixed over the K loop)
+  int b_krow[BP], b_off[BP], b_r[BP], b_s[BP], b_cls[BP];
   bool b_cok[BP];
 #pragma unroll
   for (int p = 0; p < BP; ++p) {
     const int idx = tid + 256 * p;
     const int krow = idx / BV, c4 = idx - krow * BV;
     b_krow[p] = krow;
-    if (VEC_TAP) {
+    int tap, ci;
+    if (C4) {
       const int ncol = nt * BN + 4 * c4;
-      b_tap[p] = ncol / g.Cin;
-      b_ci[p] = ncol - b_tap[p] * g.Cin;
+      tap = ncol / g.Cin;
+      ci = ncol - tap * g.Cin;
       b_cok[p] = ncol < g.Ktot;
     } else {
       const int per_tap = g.Cin / BN;
-      b_tap[p] = nt / per_tap;
-      b_ci[p] = (nt - b_tap[p] * per_tap) * BN + 4 * c4;
+      tap = nt / per_tap;
+      ci = (nt - tap * per_tap) * BN + 4 * c4;
       b_cok[p] = true;
     }
+    b_r[p] = tap / g.S - g.pad;
+    b_s[p] = tap % g.S - g.pad;
+    b_cls[p] = shift_class(ci, g.fold);
+    b_off[p] = ((b_r[p] * g.W + b_s[p]) * g.Cin + ci) * 4 + b_cls[p] * frame_bytes;
   }
 
   const int kt_begin = split * kt_per_split;
@@ -591,56 +717,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   auto load = [&](int kt) {
     const int m0 = kt * BK;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      const int idx = tid + 256 * p;
-      const int krow = idx / AV, c4 = idx - krow * AV;
-      const int m = m0 + krow;
-      ra[p] = (m < g.M) ? *reinterpret_cast<const float4*>(dy + (size_t)m * g.Cout + mt * BM + 4 * c4)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int p = 0; p < AP; ++p)  // rows past M lie past num_records (the range check covers the vector offset): zeros
+      ra[p] = buf_load16(yr, a_off[p] + m0 * g.Cout * 4, 0);
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
       const int m = m0 + b_krow[p];
-      const int mm = m < g.M ? m : 0;
-      const int n = mm / HoWo;
-      const int rem = mm - n * HoWo;
-      const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
-      const int r = b_tap[p] / g.S, s = b_tap[p] - r * g.S;
-      const int hi = ho * g.stride - g.pad + r, wi = wo * g.stride - g.pad + s;
-      const int cls = shift_class(b_ci[p], g.fold);
-      const int t = n % g.T;
-      const bool v = m < g.M && b_cok[p] && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W &&
-                     (unsigned)(t + cls) < (unsigned)g.T;
-      const size_t off = ((size_t)((n + cls) * g.H + hi) * g.W + wi) * g.Cin + b_ci[p];
-      rb[p] = v ? *reinterpret_cast<const float4*>(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool mok = m < g.M;
+      int n, rem, ho, wo;
+      if (C4) {  // up to 2^23 pixels: exact integer division
+        const int mm = mok ? m : 0;
+        n = mm / HoWo;
+        rem = mm - n * HoWo;
+        ho = rem / g.Wo;
+        wo = rem - ho * g.Wo;
+      } else {
+        fast_divmod(mok ? m : 0, HoWo, g.rcp_HoWo, n, rem);
+        fast_divmod(rem, g.Wo, g.rcp_Wo, ho, wo);
+      }
+      const int hi = ho * g.stride, wi = wo * g.stride;
+      const bool v = mok && b_cok[p] && (unsigned)(hi + b_r[p]) < (unsigned)g.H && (unsigned)(wi + b_s[p]) < (unsigned)g.W &&
+                     (unsigned)(n % g.T + b_cls[p]) < (unsigned)g.T;
+      rb[p] = buf_load16(xr, (((n * g.H + hi) * g.W + wi) * g.Cin * 4 + b_off[p]) | (v ? 0 : kOOB), 0);
     }
-  };
-  auto store = [&](int buf) {
-    float* As = smem + buf * STAGE;
-    float* Bs = As + BK * LDA;
-    store_direct<LDA, BM, AP>(As, ra, tid);
-    store_direct<LDB, BN, BP>(Bs, rb, tid);
   };
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  zero_acc<TM, TN>(acc);
 
   if (kt_begin < kt_end) {
     load(kt_begin);
-    store(0);
-    __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int cur = (kt - kt_begin) & 1;
-      if (kt + 1 < kt_end) load(kt + 1);
-      const float* As = smem + cur * STAGE;
-      mma_stage<LDA, LDB, TM, TN>(As, As + BK * LDA, acc, wm0, wn0, lane);
-      if (kt + 1 < kt_end) store(cur ^ 1);
       __syncthreads();
+      store_direct<LDA, BM, AP>(As, ra, tid);
+      store_direct<LDB, BN, BP>(Bs, rb, tid);
+      __syncthreads();
+      if (kt + 1 < kt_end) load(kt + 1);
+      mma_stage<LDA, LDB, TM, TN>(As, Bs, acc, wm0, wn0, lane);
     }
   }
 
@@ -649,7 +761,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   for (int j = 0; j < TN; ++j) {
     int col;
     bool cok = true;
-    if (VEC_TAP) {
+    if (C4) {
       col = nt * BN + wn0 + 32 * j + (lane & 31);
       cok = col < g.Ktot;
     } else {
@@ -668,13 +780,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, float beta, int splits,
-                                    int64_t numel4) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel4; i += stride) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < splits; ++k) {
+// dw = beta*dw + sum over splits (fixed order).  64 float4 elements x 4 split-lanes per block.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, float beta,
+                                                            int splits, int64_t numel4) {
+  __shared__ float4 sh[4][64];
+  const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + el;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < numel4) {
+    for (int k = sg; k < splits; k += 4) {
       const float4 v = reinterpret_cast<const float4*>(slab)[(int64_t)k * numel4 + i];
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+  }
+  sh[sg][el] = s;
+  __syncthreads();
+  if (sg == 0 && i < numel4) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float4 v = sh[k][el];
       s.x += v.x;
       s.y += v.y;
       s.z += v.z;
@@ -692,6 +819,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
+// ---- host side --------------------------------------------------------------------------------
+
 int check_geom(const bdv_conv_geom* g, const char* who) {
   BDV_REQUIRE(g != nullptr, "%s: geom is NULL", who);
   BDV_REQUIRE(g->N > 0 && g->H > 0 && g->W > 0 && g->Ho > 0 && g->Wo > 0, "%s: non-positive extent", who);
@@ -701,14 +830,19 @@ int check_geom(const bdv_conv_geom* g, const char* who) {
   BDV_REQUIRE(g->stride == 1 || g->stride == 2, "%s: stride %d unsupported", who, g->stride);
   BDV_REQUIRE(g->Ho == (g->H + 2 * g->pad - g->R) / g->stride + 1 && g->Wo == (g->W + 2 * g->pad - g->S) / g->stride + 1,
               "%s: Ho/Wo inconsistent with H/W/pad/stride", who);
-  BDV_REQUIRE(g->Cin % BK == 0 || g->Cin == 4, "%s: Cin=%d must be a multiple of 16 (or exactly 4)", who, g->Cin);
+  BDV_REQUIRE(g->Cin % BK == 0 || g->Cin == 4, "%s: Cin=%d must be a multiple of 32 (or exactly 4)", who, g->Cin);
   if (g->fold > 0) {
     BDV_REQUIRE(g->fold % 4 == 0 && 2 * g->fold <= g->Cin, "%s: fold=%d must be a multiple of 4 and <= Cin/2", who,
                 g->fold);
     BDV_REQUIRE(g->T > 0 && g->N % g->T == 0, "%s: N=%d not a multiple of T=%d", who, g->N, g->T);
+    BDV_REQUIRE(g->Cin % BK == 0, "%s: temporal shift needs Cin %% 32 == 0", who);
   }
-  BDV_REQUIRE((int64_t)g->N * g->H * g->W * g->Cin < (1ll << 31) && (int64_t)g->N * g->Ho * g->Wo * g->Cout < (1ll << 31),
-              "%s: tensor exceeds 2^31 elements", who);
+  // byte offsets are 32-bit with the top bit reserved as the out-of-range marker
+  BDV_REQUIRE((int64_t)g->N * g->H * g->W * g->Cin < (1ll << 29) && (int64_t)g->N * g->Ho * g->Wo * g->Cout < (1ll << 29),
+              "%s: tensor exceeds 2^29 elements", who);
+  BDV_REQUIRE((int64_t)g->Cout * g->R * g->S * g->Cin < (1ll << 29), "%s: weight tensor too large", who);
+  // fast_divmod (float reciprocal) is exact below 2^22 pixels; the Cin = 4 kernels use integer division instead
+  BDV_REQUIRE((int64_t)g->N * g->Ho * g->Wo < (1ll << 22) || g->Cin == 4, "%s: more than 2^22 output pixels", who);
   return BDV_OK;
 }
 
@@ -719,53 +853,44 @@ Geom make_geom(const bdv_conv_geom* g) {
   d.T = g->fold > 0 ? g->T : 1;
   d.fold = g->fold;
   d.M = 0; d.Ktot = 0;
+  d.rcp_HoWo = 1.0f / (float)(g->Ho * g->Wo);
+  d.rcp_Wo = 1.0f / (float)g->Wo;
   return d;
 }
-
-// ---- host-side planning ---------------------------------------------------------------------
 
 bool debug_plan() {
   static const bool on = getenv("BDVCIL_DEBUG_PLAN") != nullptr;
   return on;
 }
 
-// number of co-resident 256-thread blocks of `kernel` on the whole device (occupancy API x CU count)
-template <class KernelT>
-int resident_blocks(KernelT kernel) {
-  int dev = 0, cus = 256, per_cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 768;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kernel, 256, 0) != hipSuccess || per_cu <= 0) {
-    (void)hipGetLastError();
-    per_cu = 3;
-  }
-  return cus * per_cu;
-}
-
-// Pick the K-split of the remainder tiles.  A CU is MFMA-bound once it holds >= 3 blocks, so the launch time is
-// set by the CU with the most work: whole rounds of `cus` tiles run data-parallel, the last partial round
-// (r < cus tiles) is cut along K into `split` slices per tile so that its blocks spread over all CUs.
-// Cost model in microseconds: one K-iteration of a 64-accumulator block = 0.85 us of one CU's MFMA pipes;
-// a CU with 1 / 2 blocks reaches ~65 % / ~85 % of that rate; the fix-up moves 2 x seg_bytes per slice, mostly
-// through the Infinity Cache (~8 TB/s), and is latency-bound per slice.
-Work plan_work(int tiles, int nk, int W, size_t seg_bytes, size_t ws_bytes) {
-  const int cus = 256;
-  (void)W;
+// Pick the K-split of the remainder tiles.
+// Measured on MI355X (tools/ubench): 3 blocks of these kernels are resident per CU, i.e. W = 768 blocks run at a
+// time and a CU is MFMA-bound with 2-3 of them; a launch whose block count is just above a multiple of 768 pays
+// a whole extra, poorly filled round.  So whole rounds of W tiles run data-parallel and the remaining r < W tiles
+// are cut along K into `split` slices each: the tail then consists of many short blocks that fill every CU.
+// Cost model (us): one 32-deep K-iteration of a 64-accumulator block = `iter_us` of its CU's matrix pipes; a CU
+// holding 1 / 2 / 3 blocks reaches ~60 / 92 / 100 % of that rate; the fix-up costs ~10 us + 2.5 us per slice + its
+// bytes at ~8 TB/s.
+Work plan_work(int tiles, int nk, double iter_us, size_t seg_bytes, size_t ws_bytes) {
+  const int cus = 256, W = 3 * cus;
   Work wk;
-  const int q = tiles / cus, r = tiles - q * cus;
+  const int q = tiles / W, r = tiles - q * W;
   wk.dp_tiles = tiles;
   wk.rem_tiles = 0;
   wk.split = 1;
-  if (r == 0 || nk < 8) return wk;
-  auto eff = [&](int c) { return (q + c) >= 3 ? 1.0 : ((q + c) == 2 ? 0.85 : 0.65); };
+  if (r == 0 || nk < 4) return wk;
+  auto tail_time = [&](int blocks, double iters) {  // time of `blocks` equal blocks of `iters` K-iterations
+    const int full = blocks / W, rest = blocks - full * W;
+    const int c = (rest + cus - 1) / cus;            // blocks per CU in the last, partial round
+    const double e = c >= 3 ? 1.0 : (c == 2 ? 0.92 : 0.6);
+    return iters * iter_us * (3.0 * full + (c > 0 ? c / e : 0.0));
+  };
   double best = 1e30;
   int best_s = 1;
-  for (int sp = 1; sp <= 32 && nk / sp >= 4; ++sp) {
+  for (int sp = 1; sp <= 24 && nk / sp >= 2; ++sp) {
     const size_t need = (size_t)r * sp * seg_bytes;
     if (sp > 1 && need > ws_bytes) break;
-    const int c = (int)(((long long)r * sp + cus - 1) / cus);
-    double cost = c * ((double)nk / sp) * 0.85 / eff(c);
-    // fix-up launch: each thread walks the slices serially (measured ~2.5 us per slice) + launch boundary
+    double cost = tail_time(r * sp, (double)nk / sp);
     if (sp > 1) cost += 10.0 + 2.5 * sp + (double)need * 2.0 / 8.0e6;
     if (cost < best * 0.95) {  // prefer fewer slices unless clearly better
       best = cost;
@@ -773,102 +898,52 @@ Work plan_work(int tiles, int nk, int W, size_t seg_bytes, size_t ws_bytes) {
     }
   }
   if (best_s > 1) {
-    wk.dp_tiles = q * cus;
+    wk.dp_tiles = q * W;
     wk.rem_tiles = r;
     wk.split = best_s;
   }
   return wk;
 }
 
-constexpr size_t kSegBytes128 = 64 * 256 * sizeof(float);  // 128x128 or 256x64 tile: 64 accumulator regs x 256 threads
 constexpr size_t kMaxSplitWorkspace = 160ull << 20;
 
-struct WgradPlan {
-  bool small;  // 64x64 tiles
-  bool vec_tap;
-  int MTw, NTw, splits, kt_per_split;
-};
-
-WgradPlan plan_wgrad(const bdv_conv_geom* g, int W) {
-  WgradPlan p;
-  p.vec_tap = (g->Cin % BK) != 0;
-  p.small = p.vec_tap || (g->Cout % 128) != 0 || (g->Cin % 128) != 0;
-  const int bm = p.small ? 64 : 128, bn = p.small ? 64 : 128;
-  const int ktot = g->R * g->S * g->Cin;
-  p.MTw = g->Cout / bm;
-  p.NTw = p.vec_tap ? (ktot + bn - 1) / bn : g->R * g->S * (g->Cin / bn);
-  const int64_t M = (int64_t)g->N * g->Ho * g->Wo;
-  const int nkt = (int)((M + BK - 1) / BK);
-  const int tiles = p.MTw * p.NTw;
-  // blocks = tiles * splits should fill whole rounds of W co-resident blocks; more rounds = less slab traffic per
-  // flop is not true here (slab bytes grow with splits), so take the smallest round count whose fill is >= 90 %.
-  int best_s = 1;
-  double best_cost = 1e30;
-  const double dw_bytes = (double)g->Cout * ktot * 4.0;
-  for (int k = 1; k <= 4; ++k) {
-    int sp = (int)(((long long)k * W) / tiles);
-    if (sp < 1) sp = 1;
-    if (sp > 1024) sp = 1024;
-    while (sp > 1 && (nkt + sp - 1) / sp < 8) --sp;
-    const int per = (nkt + sp - 1) / sp;
-    const double rounds = (double)(((long long)tiles * sp + W - 1) / W);
-    const double t_iter = 0.85 * ((double)W / 256.0) * (p.small ? 0.3 : 1.0);
-    const double cost = rounds * per * t_iter + 4.0 + sp * dw_bytes / 4.0e6;
-    if (cost < best_cost) {
-      best_cost = cost;
-      best_s = sp;
-    }
-  }
-  int per = (nkt + best_s - 1) / best_s;
-  p.kt_per_split = per;
-  p.splits = (nkt + per - 1) / per;
-  return p;
-}
-
-int wgrad_resident(const bdv_conv_geom* g) {
-  const bool vec_tap = (g->Cin % BK) != 0;
-  const bool small = vec_tap || (g->Cout % 128) != 0 || (g->Cin % 128) != 0;
-  static const int w_big = resident_blocks(conv_wgrad_kernel<128, 128, 2, 2, false>);
-  static const int w_small = resident_blocks(conv_wgrad_kernel<64, 64, 2, 2, false>);
-  return small ? w_small : w_big;
-}
-
 struct FdPlan {
-  bool wide;  // 128x128 tile (else 256x64)
-  int MT, NT, nk, W;
+  bool wide;  // 128x128 tile (else 128x64)
+  int MT, NT, nk;
+  size_t seg_bytes;
   Work wk;
 };
 
 FdPlan plan_fprop(const Geom& g, size_t ws_bytes) {
   FdPlan p;
   p.wide = (g.Cout % 128) == 0;
-  const int bm = p.wide ? 128 : 256, bn = p.wide ? 128 : 64;
-  p.MT = (g.M + bm - 1) / bm;
+  const int bn = p.wide ? 128 : 64;
+  p.MT = (g.M + 127) / 128;
   p.NT = g.Cout / bn;
   p.nk = (g.Ktot + BK - 1) / BK;
-  const bool vec_tap = (g.Cin % BK) != 0;
-  static const int w0 = resident_blocks(conv_fprop_kernel<128, 128, 2, 2, false>);
-  static const int w1 = resident_blocks(conv_fprop_kernel<256, 64, 4, 1, false>);
-  static const int w2 = resident_blocks(conv_fprop_kernel<256, 64, 4, 1, true>);
-  p.W = p.wide ? w0 : (vec_tap ? w2 : w1);
-  p.wk = plan_work(p.MT * p.NT, p.nk, p.W, kSegBytes128, ws_bytes);
+  p.seg_bytes = (size_t)(p.wide ? 64 : 32) * 256 * sizeof(float);
+  if (g.Cin % BK != 0) {  // stem kernel: no K split
+    p.wk.dp_tiles = p.MT * p.NT;
+    p.wk.rem_tiles = 0;
+    p.wk.split = 1;
+  } else {
+    p.wk = plan_work(p.MT * p.NT, p.nk, p.wide ? 1.7 : 0.85, p.seg_bytes, ws_bytes);
+  }
   return p;
 }
 
 FdPlan plan_dgrad(const Geom& g, size_t ws_bytes) {
   FdPlan p;
   p.wide = (g.Cin % 128) == 0;
-  const int bm = p.wide ? 128 : 256, bn = p.wide ? 128 : 64;
+  const int bn = p.wide ? 128 : 64;
   const int st = g.stride;
   const int Mc0 = g.N * ((g.H + st - 1) / st) * ((g.W + st - 1) / st);  // largest parity class
-  p.MT = (Mc0 + bm - 1) / bm;
+  p.MT = (Mc0 + 127) / 128;
   p.NT = g.Cin / bn;
   p.nk = g.R * g.S * g.Cout / BK;
-  static const int w0 = resident_blocks(conv_dgrad_kernel<128, 128, 2, 2>);
-  static const int w1 = resident_blocks(conv_dgrad_kernel<256, 64, 4, 1>);
-  p.W = p.wide ? w0 : w1;
+  p.seg_bytes = (size_t)(p.wide ? 64 : 32) * 256 * sizeof(float);
   if (st == 1) {
-    p.wk = plan_work(p.MT * p.NT, p.nk, p.W, kSegBytes128, ws_bytes);
+    p.wk = plan_work(p.MT * p.NT, p.nk, p.wide ? 1.7 : 0.85, p.seg_bytes, ws_bytes);
   } else {
     p.wk.dp_tiles = ((p.MT + 7) / 8) * 8 * p.NT;  // padded grid per parity class
     p.wk.rem_tiles = 0;
@@ -877,12 +952,60 @@ FdPlan plan_dgrad(const Geom& g, size_t ws_bytes) {
   return p;
 }
 
+struct WgradPlan {
+  bool small;  // 64x64 tiles
+  bool c4;
+  int MTw, NTw, splits, kt_per_split;
+};
+
+WgradPlan plan_wgrad(const bdv_conv_geom* g) {
+  const int W = 768;
+  WgradPlan p;
+  p.c4 = (g->Cin % BK) != 0;
+  p.small = p.c4 || (g->Cout % 128) != 0 || (g->Cin % 128) != 0;
+  const int bm = p.small ? 64 : 128, bn = p.small ? 64 : 128;
+  const int ktot = g->R * g->S * g->Cin;
+  p.MTw = g->Cout / bm;
+  p.NTw = p.c4 ? (ktot + bn - 1) / bn : g->R * g->S * (g->Cin / bn);
+  const int64_t M = (int64_t)g->N * g->Ho * g->Wo;
+  const int nkt = (int)((M + BK - 1) / BK);
+  const int tiles = p.MTw * p.NTw;
+  // blocks = tiles * splits should fill whole rounds of co-resident blocks; slab bytes grow with splits
+  int best_s = 1;
+  double best_cost = 1e30;
+  const double dw_bytes = (double)g->Cout * ktot * 4.0;
+  const int Wk = p.small ? 2 * W : W;  // the 16-accumulator blocks fit twice as many per CU
+  for (int k = 1; k <= 4; ++k) {
+    int sp = (int)(((long long)k * Wk) / tiles);
+    if (sp < 1) sp = 1;
+    if (sp > 1024) sp = 1024;
+    while (sp > 1 && (nkt + sp - 1) / sp < 4) --sp;
+    const int per = (nkt + sp - 1) / sp;
+    const double rounds = (double)(((long long)tiles * sp + Wk - 1) / Wk);
+    const double t_iter = 1.7 * 3.0 * (p.small ? 0.25 : 1.0);
+    const double cost = rounds * per * t_iter + 4.0 + sp * dw_bytes / 4.0e6;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best_s = sp;
+    }
+  }
+  const int per = (nkt + best_s - 1) / best_s;
+  p.kt_per_split = per;
+  p.splits = (nkt + per - 1) / per;
+  return p;
+}
+
 }  // namespace
+
+extern "C" void bdv_debug_set(int knob, int value) {
+  (void)knob;
+  (void)value;
+}
 
 extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
   if (check_geom(gg, "bdv_conv_workspace_bytes")) return 0;
   if (kind == 2) {
-    const WgradPlan p = plan_wgrad(gg, wgrad_resident(gg));
+    const WgradPlan p = plan_wgrad(gg);
     return (size_t)p.splits * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(float);
   }
   Geom g = make_geom(gg);
@@ -897,15 +1020,14 @@ extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
     g.Ktot = g.R * g.S * g.Cout;
     p = plan_dgrad(g, kMaxSplitWorkspace);
   }
-  const size_t need = p.wk.split > 1 ? (size_t)p.wk.rem_tiles * p.wk.split * kSegBytes128 : 0;
+  const size_t need = p.wk.split > 1 ? (size_t)p.wk.rem_tiles * p.wk.split * p.seg_bytes : 0;
   return need > 16 ? need : 16;
 }
 
 extern "C" int bdv_conv_fprop_stat_rows(const bdv_conv_geom* gg) {
   if (check_geom(gg, "bdv_conv_fprop_stat_rows")) return 0;
-  const int bm = (gg->Cout % 128) == 0 ? 128 : 256;
   const int64_t M = (int64_t)gg->N * gg->Ho * gg->Wo;
-  return (int)((M + bm - 1) / bm);
+  return (int)((M + 127) / 128);
 }
 
 extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* gg, float* bn_partial,
@@ -918,24 +1040,22 @@ extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bd
   g.M = g.N * g.Ho * g.Wo;
   g.Ktot = g.R * g.S * g.Cin;
   hipStream_t s = (hipStream_t)stream;
-  const bool vec_tap = (g.Cin % BK) != 0;
-  BDV_REQUIRE(!(vec_tap && g.fold > 0), "bdv_conv_fprop: shift needs Cin %% 16 == 0");
+  const bool c4 = (g.Cin % BK) != 0;
   const FdPlan p = plan_fprop(g, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0);
   const int blocks = p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split;
   float* slab = (float*)workspace;
   if (debug_plan())
-    fprintf(stderr, "[bdv plan] fprop %dx%d Cin %d Cout %d k%d s%d: tiles %d nk %d W %d -> dp %d rem %d split %d\n", g.H, g.W,
-            g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.W, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
-  if (p.wide) {
-    if (vec_tap)
-      hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2, true>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, bn_partial, p.MT);
+    fprintf(stderr, "[bdv plan] fprop %dx%d Cin %d Cout %d k%d s%d: tiles %d nk %d -> dp %d rem %d split %d\n", g.H, g.W,
+            g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
+  if (c4) {
+    if (p.wide)
+      hipLaunchKernelGGL((conv_fprop_c4_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, bn_partial, p.MT);
     else
-      hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2, false>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, bn_partial, p.MT);
+      hipLaunchKernelGGL((conv_fprop_c4_kernel<128, 64, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, bn_partial, p.MT);
+  } else if (p.wide) {
+    hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, bn_partial, p.MT);
   } else {
-    if (vec_tap)
-      hipLaunchKernelGGL((conv_fprop_kernel<256, 64, 4, 1, true>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, bn_partial, p.MT);
-    else
-      hipLaunchKernelGGL((conv_fprop_kernel<256, 64, 4, 1, false>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, bn_partial, p.MT);
+    hipLaunchKernelGGL((conv_fprop_kernel<128, 64, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, bn_partial, p.MT);
   }
   BDV_LAUNCH_CHECK("bdv_conv_fprop");
   if (p.wk.split > 1) {
@@ -944,7 +1064,7 @@ extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bd
       hipLaunchKernelGGL((conv_fprop_fixup_kernel<128, 128, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk,
                          bn_partial, p.MT);
     else
-      hipLaunchKernelGGL((conv_fprop_fixup_kernel<256, 64, 4, 1>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk,
+      hipLaunchKernelGGL((conv_fprop_fixup_kernel<128, 64, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk,
                          bn_partial, p.MT);
     BDV_LAUNCH_CHECK("bdv_conv_fprop(fixup)");
   }
@@ -969,19 +1089,19 @@ extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const 
   const dim3 grid(p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split, st * st);
   float* slab = (float*)workspace;
   if (debug_plan())
-    fprintf(stderr, "[bdv plan] dgrad %dx%d Cin %d Cout %d k%d s%d: tiles %d nk %d W %d -> dp %d rem %d split %d\n", g.H, g.W,
-            g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.W, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
+    fprintf(stderr, "[bdv plan] dgrad %dx%d Cin %d Cout %d k%d s%d: tiles %d nk %d -> dp %d rem %d split %d\n", g.H, g.W,
+            g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
   if (p.wide)
     hipLaunchKernelGGL((conv_dgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, p.NT, p.wk, slab);
   else
-    hipLaunchKernelGGL((conv_dgrad_kernel<256, 64, 4, 1>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, p.NT, p.wk, slab);
+    hipLaunchKernelGGL((conv_dgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, p.NT, p.wk, slab);
   BDV_LAUNCH_CHECK("bdv_conv_dgrad");
   if (p.wk.split > 1) {
-    const dim3 fg(p.wk.rem_tiles, 4);
+    const dim3 fg(p.wk.rem_tiles);
     if (p.wide)
       hipLaunchKernelGGL((conv_dgrad_fixup_kernel<128, 128, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, dx, add_src, add_mask_src, g, p.NT, p.wk);
     else
-      hipLaunchKernelGGL((conv_dgrad_fixup_kernel<256, 64, 4, 1>), fg, dim3(256), 0, s, (const float*)slab, dx, add_src, add_mask_src, g, p.NT, p.wk);
+      hipLaunchKernelGGL((conv_dgrad_fixup_kernel<128, 64, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, dx, add_src, add_mask_src, g, p.NT, p.wk);
     BDV_LAUNCH_CHECK("bdv_conv_dgrad(fixup)");
   }
   return BDV_OK;
@@ -993,13 +1113,12 @@ extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float 
   BDV_REQUIRE(dy && x && dw && workspace, "bdv_conv_wgrad: null pointer");
   BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(dw) && bdv_aligned16(workspace),
               "bdv_conv_wgrad: pointers must be 16-byte aligned");
-  const WgradPlan p = plan_wgrad(gg, wgrad_resident(gg));
+  const WgradPlan p = plan_wgrad(gg);
   const size_t need = (size_t)p.splits * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(float);
   if (workspace_bytes < need) {
     bdv_set_error("bdv_conv_wgrad: workspace %zu < required %zu bytes", workspace_bytes, need);
     return BDV_EWORKSPACE;
   }
-  BDV_REQUIRE(!(p.vec_tap && gg->fold > 0), "bdv_conv_wgrad: shift needs Cin %% 16 == 0");
   Geom g = make_geom(gg);
   g.M = g.N * g.Ho * g.Wo;
   g.Ktot = g.R * g.S * g.Cin;
@@ -1007,13 +1126,12 @@ extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float 
   float* slab = (float*)workspace;
   const dim3 grid(p.MTw * p.NTw, p.splits);
   if (debug_plan())
-    fprintf(stderr, "[bdv plan] wgrad %dx%d Cin %d Cout %d k%d s%d: tiles %d W %d -> splits %d x %d k-iters (%s)\n", gg->H, gg->W,
-            gg->Cin, gg->Cout, gg->R, gg->stride, p.MTw * p.NTw, wgrad_resident(gg), p.splits, p.kt_per_split,
-            p.small ? "64x64" : "128x128");
+    fprintf(stderr, "[bdv plan] wgrad %dx%d Cin %d Cout %d k%d s%d: tiles %d -> splits %d x %d k-iters (%s)\n", gg->H, gg->W,
+            gg->Cin, gg->Cout, gg->R, gg->stride, p.MTw * p.NTw, p.splits, p.kt_per_split, p.small ? "64x64" : "128x128");
   if (!p.small) {
     hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,
                        p.kt_per_split);
-  } else if (p.vec_tap) {
+  } else if (p.c4) {
     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,
                        p.kt_per_split);
   } else {
@@ -1022,9 +1140,8 @@ extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float 
   }
   BDV_LAUNCH_CHECK("bdv_conv_wgrad");
   const int64_t numel4 = (int64_t)g.Cout * g.Ktot / 4;
-  int rb = (int)((numel4 + 255) / 256);
-  if (rb > 2048) rb = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, (const float*)slab, dw, beta, p.splits, numel4);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((numel4 + 63) / 64)), dim3(256), 0, s, (const float*)slab, dw, beta, p.splits,
+                     numel4);
   BDV_LAUNCH_CHECK("bdv_conv_wgrad(reduce)");
   return BDV_OK;
 }

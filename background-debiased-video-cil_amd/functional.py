@@ -28,9 +28,11 @@ from . import kernels as K
 # Launching the wgrads on a second HIP stream keeps two independent kernels in flight, so the CUs a kernel's last
 # partial wave of workgroups leaves idle (tile-count quantisation on 256 CUs) are filled by the other kernel, and the
 # HBM-bound BN-backward passes overlap the MFMA-bound wgrad.  ``join_side_stream`` must run before gradients are
-# consumed (FusedSGD.step / clip / GradAllReducer / StemFn.backward do it).
+# consumed (FusedSGD.step / clip / GradAllReducer / StemFn.backward do it).  Off by default since the 32-deep
+# single-stage conv kernels: the gain shrank to ~1 % and concurrent kernels blur per-kernel timing; enable with
+# BDVCIL_WGRAD_SIDE_STREAM=1.
 import os as _os
-_SIDE = {'enabled': _os.environ.get('BDVCIL_WGRAD_SIDE_STREAM', '1') != '0', 'streams': {}, 'pending': {}}
+_SIDE = {'enabled': _os.environ.get('BDVCIL_WGRAD_SIDE_STREAM', '0') != '0', 'streams': {}, 'pending': {}}
 
 
 def set_side_stream_enabled(flag: bool):

@@ -53,10 +53,12 @@ class ConvTimer:
 
         def kernel_tag(kind, g):
             if kind == 'fprop':
-                return 'conv_fprop_kernel<128,128,2,2>' if g.Cout % 128 == 0 else 'conv_fprop_kernel<256,64,4,1>'
+                if g.Cin == 4:
+                    return 'conv_fprop_c4_kernel<128,64,2,2>'
+                return 'conv_fprop_kernel<128,128,2,2>' if g.Cout % 128 == 0 else 'conv_fprop_kernel<128,64,2,2>'
             if kind == 'dgrad':
-                return 'conv_dgrad_kernel<128,128,2,2>' if g.Cin % 128 == 0 else 'conv_dgrad_kernel<256,64,4,1>'
-            small = (g.Cin % 16 != 0) or (g.Cout % 128 != 0) or (g.Cin % 128 != 0)
+                return 'conv_dgrad_kernel<128,128,2,2>' if g.Cin % 128 == 0 else 'conv_dgrad_kernel<128,64,2,2>'
+            small = (g.Cin % 32 != 0) or (g.Cout % 128 != 0) or (g.Cin % 128 != 0)
             return 'conv_wgrad_kernel<64,64,2,2>' if small else 'conv_wgrad_kernel<128,128,2,2>'
 
         def make(kind, fn, geom_pos):
