@@ -180,29 +180,70 @@ __device__ __forceinline__ void fprop_store(float* __restrict__ y, const Geom& g
   if (row < g.M) y[(size_t)row * g.Cout + col] = v;
 }
 
-// dgrad element store: temporal un-shift scatter + optional masked residual add (see kernel comment)
-__device__ __forceinline__ void dgrad_store(float* __restrict__ dx, const float* __restrict__ add_src,
-                                            const uint32_t* __restrict__ add_mask, const Geom& g, int HW, int row, int n_hint,
-                                            bool have_n, int col, float v) {
+// dgrad store of 4 consecutive input channels of pixel `row`: temporal un-shift scatter + optional masked
+// residual add (see the kernel comment).  col % 4 == 0 and fold % 4 == 0, so the 4 channels share a shift class.
+__device__ __forceinline__ void dgrad_store4(float* __restrict__ dx, const float* __restrict__ add_src,
+                                             const uint32_t* __restrict__ add_mask, const Geom& g, int HW, float rcp_HW,
+                                             int row, int col, float4 v) {
   const int cls = shift_class(col, g.fold);
   int drow = row;
   if (cls != 0) {
-    const int n = have_n ? n_hint : row / HW;
+    int n, rem;
+    fast_divmod(row, HW, rcp_HW, n, rem);
     const int t = n % g.T;
     if ((unsigned)(t + cls) < (unsigned)g.T) {
       drow = row + cls * HW;
     } else {
       drow = row - cls * (g.T - 1) * HW;
-      v = 0.f;
+      v = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   const size_t o = (size_t)drow * g.Cin + col;
   if (add_src != nullptr) {
-    float a = add_src[o];
-    if (add_mask != nullptr && !((add_mask[o >> 5] >> (o & 31)) & 1u)) a = 0.f;
-    v += a;
+    float4 a = *reinterpret_cast<const float4*>(add_src + o);
+    if (add_mask != nullptr) {
+      const unsigned nib = (add_mask[o >> 5] >> (o & 31)) & 0xFu;
+      a.x = (nib & 1u) ? a.x : 0.f;
+      a.y = (nib & 2u) ? a.y : 0.f;
+      a.z = (nib & 4u) ? a.z : 0.f;
+      a.w = (nib & 8u) ? a.w : 0.f;
+    }
+    v.x += a.x;
+    v.y += a.y;
+    v.z += a.z;
+    v.w += a.w;
   }
-  dx[o] = v;
+  *reinterpret_cast<float4*>(dx + o) = v;
+}
+
+// Epilogue staging: the accumulator layout (one column per lane, 16 rows in registers) would store 4 bytes per
+// lane; going through the (now free) LDS stage turns the tile into row-major order so that every thread handles
+// 16-byte pieces of a row: 4x fewer, 4x wider global instructions (the 1x1 convs with wide outputs are bound by
+// this traffic, not by MFMA).  Two passes of WM*32 rows; emit(row_in_tile, col_in_tile, float4).
+template <int BM, int BN, int WM, int WN, class F>
+__device__ __forceinline__ void staged_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ smem, int tid,
+                                                F&& emit) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int V = BN / 4;                     // float4 per row
+  constexpr int PER = WM * 32 * V / 256;        // float4 per thread per pass
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn0 = (wave % WN) * (BN / WN);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    __syncthreads();  // LDS is free: K loop / previous pass finished
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) smem[(wm * 32 + acc_row(e, lane)) * BN + wn0 + 32 * j + (lane & 31)] = acc[i][j][e];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int idx = tid + 256 * q;
+      const int lr = idx / V, c4 = idx - lr * V;
+      const float4 v = *reinterpret_cast<const float4*>(smem + lr * BN + 4 * c4);
+      emit((lr >> 5) * (BM / WM) + 32 * i + (lr & 31), 4 * c4, v);
+    }
+  }
 }
 
 // BatchNorm batch statistics fused into the fprop epilogue: per tile, the column sums of y and y^2 over the
@@ -246,27 +287,28 @@ __device__ __forceinline__ void fprop_epilogue(const f32x16 (&acc)[BM / WM / 32]
                                                int mt, int nt, int tid) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
-  float cs[TN], cq[TN];
+  const int wm0 = (wave / WN) * (BM / WM);
+  staged_epilogue<BM, BN, WM, WN>(acc, smem, tid, [&](int tr, int tc, float4 v) {
+    const int row = mt * BM + tr;
+    if (row < g.M) *reinterpret_cast<float4*>(y + (size_t)row * g.Cout + nt * BN + tc) = v;
+  });
+  if (bn_partial != nullptr) {
+    float cs[TN], cq[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) cs[j] = cq[j] = 0.f;
+    for (int j = 0; j < TN; ++j) cs[j] = cq[j] = 0.f;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = nt * BN + wn0 + 32 * j + (lane & 31);
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
-        const float v = acc[i][j][e];
-        fprop_store(y, g, row, col, v);
-        if (row < g.M) {
+        for (int e = 0; e < 16; ++e) {
+          const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
+          const float v = row < g.M ? acc[i][j][e] : 0.f;
           cs[j] += v;
           cq[j] += v * v;
         }
-      }
-    }
-  if (bn_partial != nullptr) tile_colstats<BM, BN, WM, WN>(smem, cs, cq, bn_partial, MT, g.Cout, mt, nt, tid);
+    tile_colstats<BM, BN, WM, WN>(smem, cs, cq, bn_partial, MT, g.Cout, mt, nt, tid);
+  }
 }
 
 // =========================================================================================
@@ -443,7 +485,7 @@ __global__ __launch_bounds__(256) void conv_fprop_fixup_kernel(const float* __re
                                                                 int NT, Work wk, float* __restrict__ bn_partial, int MT) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NACC = TM * TN * 16;
-  __shared__ float smem[2 * WM * BN];
+  __shared__ __attribute__((aligned(16))) float smem[WM * 32 * BN];
   const int rt = blockIdx.x, tile = wk.dp_tiles + rt;
   const int mt = tile / NT, nt = tile - mt * NT;
   const int tid = threadIdx.x;
@@ -478,7 +520,8 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
   constexpr int AP = BM / 32, BP = BN / 32;
   constexpr int BV = BN / 4;
   constexpr int AOFF = (BK * LDA + 3) & ~3;  // keep the B image 16-byte aligned
-  __shared__ __attribute__((aligned(16))) float smem[AOFF + BK * LDB];
+  constexpr int SMEM = (AOFF + BK * LDB) > (WM * 32 * BN) ? (AOFF + BK * LDB) : (WM * 32 * BN);
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
   float* const As = smem;
   float* const Bs = smem + AOFF;
 
@@ -521,6 +564,7 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
   const int HW = g.H * g.W;
   const int RS = g.R * g.S;
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.N * g.Ho * g.Wo * g.Cout * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, g.Cout * RS * g.Cin * 4, 0x00020000);
 
   int a_base[AP], a_h[AP], a_w[AP];
 #pragma unroll
@@ -541,7 +585,7 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
   for (int p = 0; p < BP; ++p) {
     const int idx = tid + 256 * p;
     const int krow = idx / BV, c4 = idx - krow * BV;
-    b_base[p] = krow * RS * g.Cin + nt * BN + 4 * c4;
+    b_base[p] = (krow * RS * g.Cin + nt * BN + 4 * c4) * 4;
   }
 
   // K index state (uniform): kt = chunk * ntap + ir * ns + is  (tap-fastest)
@@ -556,14 +600,14 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
   auto load = [&]() {
     const int tap = (r0 + ir * st) * g.S + (s0 + is * st);
     const int koff_a = (chunk * BK - (ir * g.Wo + is) * g.Cout) * 4;
-    const int koff_b = (chunk * BK * RS + tap) * g.Cin;
+    const int koff_b = (chunk * BK * RS + tap) * g.Cin * 4;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       const bool v = (unsigned)(a_h[p] - ir) < (unsigned)g.Ho && (unsigned)(a_w[p] - is) < (unsigned)g.Wo;
       ra[p] = buf_load16(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB), 0);
     }
 #pragma unroll
-    for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const float4*>(w + (size_t)(b_base[p] + koff_b));
+    for (int p = 0; p < BP; ++p) rb[p] = buf_load16(wr, b_base[p], koff_b);
     is += 1;
     const int w1 = (is == ns) ? 1 : 0;
     is = w1 ? 0 : is;
@@ -596,23 +640,19 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
   // frame n + cls when that frame is inside the clip.  Rows whose target falls outside the clip
   // ("orphans") instead write the zero that the unreachable frame at the other clip end needs,
   // which makes the scatter a bijection over dx.
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int mrow = mt * BM + wm0 + 32 * i + acc_row(e, lane);
-      if (mrow >= Mc) continue;
-      int row = mrow, n = 0;
-      if (st != 1) {
-        n = mrow / HcWc;
-        const int rem = mrow - n * HcWc;
-        const int hc = rem / Wc;
-        row = (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        dgrad_store(dx, add_src, add_mask, g, HW, row, n, st != 1, nt * BN + wn0 + 32 * j + (lane & 31), acc[i][j][e]);
+  const float rcp_HW = 1.0f / (float)HW;
+  staged_epilogue<BM, BN, WM, WN>(acc, smem, tid, [&](int tr, int tc, float4 v) {
+    const int mrow = mt * BM + tr;
+    if (mrow >= Mc) return;
+    int row = mrow;
+    if (st != 1) {
+      const int n = mrow / HcWc;
+      const int rem = mrow - n * HcWc;
+      const int hc = rem / Wc;
+      row = (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
     }
+    dgrad_store4(dx, add_src, add_mask, g, HW, rcp_HW, row, nt * BN + tc, v);
+  });
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -621,11 +661,12 @@ __global__ __launch_bounds__(256) void conv_dgrad_fixup_kernel(const float* __re
                                                                 const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NACC = TM * TN * 16;
+  __shared__ __attribute__((aligned(16))) float smem[WM * 32 * BN];
   const int rt = blockIdx.x, tile = wk.dp_tiles + rt;
   const int mt = tile / NT, nt = tile - mt * NT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int tid = threadIdx.x;
   const int HW = g.H * g.W;
+  const float rcp_HW = 1.0f / (float)HW;
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   for (int sl = 0; sl < wk.split; ++sl) {
@@ -637,16 +678,10 @@ __global__ __launch_bounds__(256) void conv_dgrad_fixup_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] += src[(size_t)((i * TN + j) * 16 + e) * 256];
   }
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
-      if (row >= g.M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        dgrad_store(dx, add_src, add_mask, g, HW, row, 0, false, nt * BN + wn0 + 32 * j + (lane & 31), acc[i][j][e]);
-    }
+  staged_epilogue<BM, BN, WM, WN>(acc, smem, tid, [&](int tr, int tc, float4 v) {
+    const int row = mt * BM + tr;
+    if (row < g.M) dgrad_store4(dx, add_src, add_mask, g, HW, rcp_HW, row, nt * BN + tc, v);
+  });
 }
 
 // =========================================================================================
