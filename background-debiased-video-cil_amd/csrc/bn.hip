@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int RB,
                                                                int64_t M, int C, const float* __restrict__ gamma,
                                                                const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, float beta_acc, float* __restrict__ coef) {
+                                                               float* __restrict__ dbeta, float beta_acc, float* __restrict__ coef,
+                                                               const float* __restrict__ mean, float* __restrict__ fused) {
   __shared__ double sh[2][64][5];
   const int c = blockIdx.x * 4 + (threadIdx.x & 3), rl = threadIdx.x >> 2;
   double s1, s2;
@@ -236,9 +237,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   if (rl != 0 || c >= C) return;
   if (dgamma != nullptr) dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)s2;
   if (dbeta != nullptr) dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)s1;
-  coef[c] = gamma[c] * invstd[c];
+  const float a = gamma[c] * invstd[c];
+  coef[c] = a;
   coef[C + c] = (float)(s1 / (double)M);
   coef[2 * C + c] = (float)(s2 / (double)M);
+  if (fused != nullptr) {  // dy = A*g - Bc*(y - mean) - Cc, consumed by the conv dgrad / wgrad operand loaders
+    fused[c] = a;
+    fused[C + c] = (float)((double)a * (double)invstd[c] * (s2 / (double)M));
+    fused[2 * C + c] = (float)((double)a * (s1 / (double)M));
+    fused[3 * C + c] = mean[c];
+  }
 }
 
 template <bool RELU>
@@ -367,14 +375,15 @@ extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shi
 }
 
 extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, const float* y, const float* gamma,
-                               const float* save_mean, const float* save_invstd, float* dy, float* dgamma, float* dbeta,
-                               float beta_acc, int64_t M, int C, int relu, void* workspace, size_t workspace_bytes,
-                               void* stream) {
-  BDV_REQUIRE(dout && y && gamma && save_mean && save_invstd && dy && workspace, "bdv_bn_backward: null pointer");
+                               const float* save_mean, const float* save_invstd, float* dy, float* fused_coef, float* dgamma,
+                               float* dbeta, float beta_acc, int64_t M, int C, int relu, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  BDV_REQUIRE(dout && y && gamma && save_mean && save_invstd && workspace, "bdv_bn_backward: null pointer");
+  BDV_REQUIRE(dy || fused_coef, "bdv_bn_backward: give dy and/or fused_coef");
   BDV_REQUIRE(!relu || (relu_mask && C % 32 == 0), "bdv_bn_backward: relu needs the forward ReLU mask (C %% 32 == 0)");
   BDV_REQUIRE(M > 0 && bn_c_ok(C), "bdv_bn_backward: unsupported M=%lld C=%d", (long long)M, C);
   BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(y) && bdv_aligned16(dy) && bdv_aligned16(workspace) &&
-                  bdv_aligned16(save_mean) && bdv_aligned16(save_invstd), "bdv_bn_backward: alignment");
+                  bdv_aligned16(save_mean) && bdv_aligned16(save_invstd) && bdv_aligned16(fused_coef), "bdv_bn_backward: alignment");
   if (workspace_bytes < bdv_bn_workspace_bytes(M, C)) {
     bdv_set_error("bdv_bn_backward: workspace too small");
     return BDV_EWORKSPACE;
@@ -392,8 +401,9 @@ extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, con
                        p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
   BDV_LAUNCH_CHECK("bdv_bn_backward(partial)");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)p1, (const float*)p2, b.RB,
-                     M, C, gamma, save_invstd, dgamma, dbeta, beta_acc, coef);
+                     M, C, gamma, save_invstd, dgamma, dbeta, beta_acc, coef, save_mean, fused_coef);
   BDV_LAUNCH_CHECK("bdv_bn_backward(finalize)");
+  if (dy == nullptr) return BDV_OK;
   const int64_t n4 = M * C / 4;
   const dim3 grid(ew_grid(n4)), blk(256);
   if (relu)

@@ -35,6 +35,13 @@ import os as _os
 _SIDE = {'enabled': _os.environ.get('BDVCIL_WGRAD_SIDE_STREAM', '0') != '0', 'streams': {}, 'pending': {}}
 
 
+# BatchNorm backward apply step inside the wgrad kernel (bdv_conv_wgrad with a bdv_bn_bwd_fuse).  It removes the
+# separate apply kernel (3 passes over the conv output) but the wgrad then reads two tensors instead of one and writes
+# dy, i.e. it only saves one pass in four, and the heavier loader costs the wgrad kernels more than that on MI355X
+# (measured on TSM-R50 bs32: 395 clips/s fused vs 400 unfused).  Off by default; BDVCIL_FUSE_BN_BWD=1 enables it.
+FUSE_BN_BWD = _os.environ.get('BDVCIL_FUSE_BN_BWD', '0') != '0'
+
+
 def set_side_stream_enabled(flag: bool):
     _SIDE['enabled'] = bool(flag)
 
@@ -118,6 +125,20 @@ def _conv_bn_forward(x, w_krsc, g, bn, gamma, beta, training):
     y = K.conv_fprop(x, w_krsc, g)
     scale, shift = K.bn_eval_params(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
     return y, None, None, scale, shift
+
+
+def _bn_wgrad_backward(dout, mask, y, gamma, mean, invstd, inp, geom, need_dw):
+    """BatchNorm(+ReLU) backward of one conv+BN unit followed by the conv's wgrad -> (dy, dgamma, dbeta, dw | None).
+    With a weight gradient wanted (and no side stream) only the BN reductions run as their own kernels; the
+    elementwise apply step happens inside the wgrad kernel, which also writes dy for the dgrad."""
+    if need_dw and not _SIDE['enabled'] and FUSE_BN_BWD:
+        coef, dg, db = K.bn_backward(dout, mask, y, gamma, mean, invstd, True, reduce_only=True)
+        dy = torch.empty_like(y)
+        dw = K.conv_wgrad(None, inp, geom, bn_fuse=(dout, mask, y, coef, dy))
+        return dy, dg, db, dw
+    dy, dg, db = K.bn_backward(dout, mask, y, gamma, mean, invstd, True)
+    dw = wgrad_overlapped(dy, inp, geom) if need_dw else None
+    return dy, dg, db, dw
 
 
 class StemFn(torch.autograd.Function):
@@ -232,11 +253,12 @@ class ResBlockFn(torch.autograd.Function):
         d = dout
         for i in range(n_main - 1, -1, -1):
             wt, gm = params[3 * i], params[3 * i + 1]
-            dy, dg, db = K.bn_backward(d, masks[i], ys[i], gm, means[i], invstds[i], True)
-            grads[3 * i + 1], grads[3 * i + 2] = dg, db
             inp = acts[i - 1] if i > 0 else x
-            if need[3 + 3 * i]:
-                grads[3 * i] = wgrad_overlapped(dy, inp, ctx.geoms[i]).permute(0, 3, 1, 2)
+            dy, dg, db, dw = _bn_wgrad_backward(d, masks[i], ys[i], gm, means[i], invstds[i], inp, ctx.geoms[i],
+                                                need[3 + 3 * i])
+            grads[3 * i + 1], grads[3 * i + 2] = dg, db
+            if dw is not None:
+                grads[3 * i] = dw.permute(0, 3, 1, 2)
             if i > 0:
                 d = K.conv_dgrad(dy, weight_krsc(wt), ctx.geoms[i])
             else:
@@ -248,10 +270,10 @@ class ResBlockFn(torch.autograd.Function):
             wd, gd = params[3 * n_main], params[3 * n_main + 1]
             gdn = ctx.geoms[n_main]
             # gradient entering the downsample BN is dout * (out > 0): same mask as the block output
-            dyd, dgd, dbd = K.bn_backward(dout, out_mask, yd, gd, mean_d, invstd_d, True)
+            dyd, dgd, dbd, dwd = _bn_wgrad_backward(dout, out_mask, yd, gd, mean_d, invstd_d, x, gdn, need[3 + 3 * n_main])
             grads[3 * n_main + 1], grads[3 * n_main + 2] = dgd, dbd
-            if need[3 + 3 * n_main]:
-                grads[3 * n_main] = wgrad_overlapped(dyd, x, gdn).permute(0, 3, 1, 2)
+            if dwd is not None:
+                grads[3 * n_main] = dwd.permute(0, 3, 1, 2)
             if need_dx:
                 dx_id = K.conv_dgrad(dyd, weight_krsc(wd), gdn)
                 dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), ctx.geoms[0], add_src=dx_id)
