@@ -710,8 +710,15 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
   float* const As = smem;
   float* const Bs = smem + BK * LDA;
 
-  const int mt = blockIdx.x % MTw, nt = blockIdx.x / MTw;
-  const int split = blockIdx.y;
+  // All tiles of one K slice read the same rows of dy and (up to the filter halo) of x.  Work index w = slice * tiles + tile,
+  // handed out so that one XCD gets a contiguous range of w: the tiles of a slice then run at the same time behind the
+  // same L2 and each operand row is fetched from the fabric about once instead of once per tile (measured before the
+  // remap: 0.77 GB fetched per launch of the 128x128 kernel, 2-4 GB for the 64-channel layers and the stem).
+  const int tiles = MTw * NTw;
+  const int wi = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = wi / tiles;
+  const int tile = wi - split * tiles;
+  const int mt = tile % MTw, nt = tile / MTw;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
@@ -1224,7 +1231,7 @@ extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float 
   g.Ktot = g.R * g.S * g.Cin;
   hipStream_t s = (hipStream_t)stream;
   float* slab = (float*)workspace;
-  const dim3 grid(p.MTw * p.NTw, p.splits);
+  const dim3 grid(p.MTw * p.NTw * p.splits);
   if (debug_plan())
     fprintf(stderr, "[bdv plan] wgrad %dx%d Cin %d Cout %d k%d s%d: tiles %d -> splits %d x %d k-iters (%s)\n", gg->H, gg->W,
             gg->Cin, gg->Cout, gg->R, gg->stride, p.MTw * p.NTw, p.splits, p.kt_per_split, p.small ? "64x64" : "128x128");

@@ -91,6 +91,23 @@ class ConvTimer:
         return by
 
 
+def pmc_traffic(tag):
+    """HBM-side bytes per launch of kernel ``tag`` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_traffic.json, produced by tools/run_profile.sh + tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
+    separate passes, KiB units, FETCH_SIZE doubled on gfx950).  None when the file has no entry."""
+    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        kernels = json.load(f).get('kernels', {})
+    want = tag.replace(' ', '')
+    for name, v in kernels.items():
+        n = name.replace(' ', '')
+        if n == want or n.startswith(want[:-1] + ','):      # wgrad carries two more template flags
+            return v.get('hbm_bytes_per_launch')
+    return None
+
+
 def cpu_baseline(depth, num_classes, head, loss, budget_s=25.0):
     """The CPU oracle (pure-torch restatement of the reference path; the reference's own trainer needs mmaction2 /
     Lightning, which do not exist here) timed on the host cores: fwd + bwd + SGD step, fp32, bounded sample."""
@@ -220,7 +237,10 @@ def main():
             tot_fl = sum(v['flops'] for v in by.values())
             res['roofline'] = {
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(PEAK_F32_MFMA / 1e12, 1), 'unit': 'TFLOP/s',
-                'frac': round(achieved * 1e12 / PEAK_F32_MFMA, 4), 'traffic': None,
+                'frac': round(achieved * 1e12 / PEAK_F32_MFMA, 4), 'traffic': pmc_traffic(dom),
+                'traffic_note': 'HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of '
+                                'this command, profiles/r01_traffic.json); avg_launch_ms spans the whole C-ABI call '
+                                '(main kernel + its K-split fix-up / slab reduce when the planner uses one)',
                 'kernel': dom, 'launches_per_step': d['launches'] // args.steps,
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                 'algorithmic_gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 2),
