@@ -25,5 +25,6 @@ from .optim import (CILTSMOptimizerConstructor, CILTSMOptimizerConstructorImprov
 from .frontend import BackgroundMixFrontEnd  # noqa: F401
 from .cil_step import TrainEngine, base_training_step, icarl_training_step  # noqa: F401
 from .ddp import GradAllReducer, broadcast_parameters  # noqa: F401
+from .representation import Herding, ReprPredictor, class_means_from_repr, nme_classify  # noqa: F401
 
 __version__ = '0.1.0'

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -71,6 +71,12 @@ SIGNATURES = {
     'bdv_icarl_targets': (c_int, [P, P, c_int, P, c_int, c_int, P]),
     'bdv_softmax_mean': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_topk_acc': (c_int, [P, P, P, c_int, c_int, P]),
+    'bdv_repr_from_features': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_nme_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'bdv_nme_classify': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'bdv_class_means': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'bdv_herding_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'bdv_herding_select': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     'bdv_reduce_workspace_bytes': (c_size_t, []),
     'bdv_kd_mse_fwd': (c_int, [P, P, P, c_int64, P, c_size_t, P]),
     'bdv_kd_mse_bwd': (c_int, [P, P, P, c_float, P, c_int64, P]),

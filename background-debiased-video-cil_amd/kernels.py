@@ -534,3 +534,61 @@ def clip_coef(sqnorm, grad_scale, max_norm, coef):
 def multi_sgd(param_ptrs, grad_ptrs, buf_ptrs, numels, lrs, wds, ntensors, momentum, grad_scale, coef):
     check(lib().bdv_multi_sgd(_p(param_ptrs), _p(grad_ptrs), _p(buf_ptrs), _p(numels), _p(lrs), _p(wds), ntensors,
                               float(momentum), float(grad_scale), _p(coef), _stream()), 'bdv_multi_sgd')
+
+
+# ---------------------------------------------------------------------------------------------
+# representation path (clip representations, NME classifier, class means, herding)
+# ---------------------------------------------------------------------------------------------
+
+def repr_from_features(feat, B, crops, T):
+    """feat (B*crops*T, D) -> (repr (B, crops, D), mean_crops (B, D)); libs/cil/cil.py:501-506,:564-571."""
+    _chk(feat, name='feat')
+    if feat.dim() != 2 or feat.shape[0] != B * crops * T:
+        raise ValueError(f'repr_from_features: feat {tuple(feat.shape)} is not (B*crops*T = {B * crops * T}, D)')
+    D = feat.shape[1]
+    rp = torch.empty((B, crops, D), dtype=torch.float32, device=feat.device)
+    mc = torch.empty((B, D), dtype=torch.float32, device=feat.device)
+    check(lib().bdv_repr_from_features(_p(feat), _p(rp), _p(mc), B, crops, T, D, _stream()), 'bdv_repr_from_features')
+    return rp, mc
+
+
+def nme_classify(repr_, class_means):
+    """repr_ (S, crops, D), class_means (K, D) -> (similarity (S, K), pred (S,) int64); libs/cil/cil.py:945-960."""
+    _chk(repr_, name='repr_')
+    _chk(class_means, name='class_means')
+    if repr_.dim() != 3 or class_means.dim() != 2 or repr_.shape[2] != class_means.shape[1]:
+        raise ValueError(f'nme_classify: repr_ {tuple(repr_.shape)} vs class_means {tuple(class_means.shape)}')
+    S, crops, D = repr_.shape
+    Kc = class_means.shape[0]
+    sim = torch.empty((S, Kc), dtype=torch.float32, device=repr_.device)
+    pred = torch.empty((S,), dtype=torch.int64, device=repr_.device)
+    ws = workspace(lib().bdv_nme_workspace_bytes(Kc, D), repr_.device, 'nme')
+    check(lib().bdv_nme_classify(_p(repr_), _p(class_means), _p(sim), _p(pred), S, crops, D, Kc, _p(ws), ws.numel(), _stream()),
+          'bdv_nme_classify')
+    return sim, pred
+
+
+def class_means(repr_, labels, num_classes):
+    """repr_ (n, D), labels (n,) int64 -> (num_classes, D) per-class means; libs/cil/cil.py:1079-1083."""
+    _chk(repr_, name='repr_')
+    _chk(labels, (repr_.shape[0],), dtype=torch.int64, name='labels')
+    n, D = repr_.shape
+    out = torch.empty((num_classes, D), dtype=torch.float32, device=repr_.device)
+    check(lib().bdv_class_means(_p(repr_), _p(labels), _p(out), n, D, int(num_classes), _stream()), 'bdv_class_means')
+    return out
+
+
+def herding_select(features, num_exemplars, cosine_distance):
+    """features (n, D) of one class -> (class_mean (1, D), indices (m,) int64, dist (m,)); memory_selection.py:70-92."""
+    _chk(features, name='features')
+    if features.dim() != 2:
+        raise ValueError(f'herding_select: features must be (n, D), got {tuple(features.shape)}')
+    n, D = features.shape
+    m = int(num_exemplars)
+    cm = torch.empty((1, D), dtype=torch.float32, device=features.device)
+    idx = torch.empty((max(m, 1),), dtype=torch.int64, device=features.device)
+    dist = torch.empty((max(m, 1),), dtype=torch.float32, device=features.device)
+    ws = workspace(lib().bdv_herding_workspace_bytes(n, D), features.device, 'herding')
+    check(lib().bdv_herding_select(_p(features), n, D, m, int(bool(cosine_distance)), _p(cm), _p(idx), _p(dist), _p(ws),
+                                   ws.numel(), _stream()), 'bdv_herding_select')
+    return cm, idx[:m], dist[:m]

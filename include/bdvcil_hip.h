@@ -191,6 +191,29 @@ int bdv_kd_mse_fwd(const float* cur, const float* prev, float* mse, int64_t nume
 int bdv_kd_mse_bwd(const float* cur, const float* prev, const float* gscale_dev, float gscale_host,
                    float* dcur, int64_t numel, void* stream);
 
+/* ---- representation path: clip representations, NME classifier, class means, herding --------- */
+/* libs/cil/cil.py:501-506 (_extract_repr) + :564-571 (predict_step, extract_repr): feat = the hooked
+ * cls_head.avg_pool output flattened to (B*crops*T, D); repr (B*crops, D) = F.normalize(mean over the T segments);
+ * mean_crops (B, D) = mean over crops of repr. */
+int bdv_repr_from_features(const float* feat, float* repr, float* mean_crops, int B, int crops, int T, int D,
+                           void* stream);
+/* libs/cil/cil.py:945-960 (NME): similarity (S,K) = mean over crops of F.cosine_similarity(repr, class_means)
+ * (each norm clamped at 1e-8), pred (S) = first arg-max over K.  repr (S*crops, D), class_means (K, D). */
+size_t bdv_nme_workspace_bytes(int K, int D);
+int bdv_nme_classify(const float* repr, const float* class_means, float* similarity, int64_t* pred, int S,
+                     int crops, int D, int K, void* workspace, size_t workspace_bytes, void* stream);
+/* libs/cil/cil.py:1079-1083: means[k] = mean of the rows of repr (n, D) whose label is k (NaN for an empty class,
+ * like torch.mean of an empty selection). */
+int bdv_class_means(const float* repr, const int64_t* labels, float* means, int n, int D, int K, void* stream);
+/* libs/cil/memory_selection.py:70-92 + :150-164 (Herding, one class): greedy selection of num_exemplars rows of
+ * features (n, D) whose running mean stays closest to the class mean (cosine: 1 - cos, else pairwise L2 distance with
+ * torch's 1e-6).  class_mean (D) is what calc_mean_features returns; indices are positions in `features` in
+ * selection order (ties -> lowest index, like argmin on the shrinking tensor); dist are the winning distances. */
+size_t bdv_herding_workspace_bytes(int n, int D);
+int bdv_herding_select(const float* features, int n, int D, int num_exemplars, int cosine_distance,
+                       float* class_mean, int64_t* indices, float* dist, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 /* ---- optimizer: multi-tensor global-norm clip + SGD(momentum, wd) ---------------------------
  * torch.optim.SGD built at libs/cil/cil.py:467 with the groups of libs/models/cil_heads/tsm.py:273-303
  * and PL gradient_clip_val (cil.py:743).  Tables are device arrays, one entry per tensor. */

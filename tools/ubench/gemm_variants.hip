@@ -120,7 +120,9 @@ int main() {
   float* h = (float*)malloc(na * 4);
   for (size_t i = 0; i < na; ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
   hipMemcpy(A, h, na * 4, hipMemcpyHostToDevice); hipMemcpy(B, h, nb * 4, hipMemcpyHostToDevice);
-  run<128, 128, 2, 2, 16, 2>("128x128 BK16 2buf (current)", K, A, B, d, ld);
+  run<128, 128, 2, 2, 64, 1>("128x128 BK64 1buf", K, A, B, d, ld);
+  run<256, 128, 4, 2, 64, 1>("256x128 8w(64x64) BK64 1buf", K, A, B, d, ld);
+  run<128, 128, 2, 2, 16, 2>("128x128 BK16 2buf (old)", K, A, B, d, ld);
   run<128, 128, 2, 2, 32, 1>("128x128 BK32 1buf", K, A, B, d, ld);
   run<128, 128, 2, 2, 32, 2>("128x128 BK32 2buf", K, A, B, d, ld);
   run<256, 128, 2, 2, 16, 2>("256x128 4w(128x64) BK16 2buf", K, A, B, d, ld);
