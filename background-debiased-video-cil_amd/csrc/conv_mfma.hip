@@ -52,7 +52,11 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int
   }
 }
 
-template <int LDA, int LDB, int TM, int TN>
+// The TM (TN) MFMA tiles of a wave are MS (NS) = 32 * waves-per-dimension rows apart ("interleaved" wave tiling:
+// wave w owns rows 32w..32w+31 of every 32*WM-row group).  With an unpadded 128-float LDS row a tile pair is then 64
+// dwords apart and a K pair 256 dwords, which is what lets the compiler address all 32 operand reads of a stage as
+// ds_read2st64_b32 with immediate offsets from one base register instead of one v_add per read.
+template <int LDA, int LDB, int TM, int TN, int MS, int NS>
 __device__ __forceinline__ void mma_stage(const float* __restrict__ As, const float* __restrict__ Bs,
                                           f32x16 (&acc)[TM][TN], int wm0, int wn0, int lane) {
   const int r = lane & 31, h = lane >> 5;
@@ -61,17 +65,17 @@ __device__ __forceinline__ void mma_stage(const float* __restrict__ As, const fl
   // operand fragments are fetched one K-pair ahead of the MFMAs that consume them
   float a[2][TM], b[2][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) a[0][i] = ap[32 * i];
+  for (int i = 0; i < TM; ++i) a[0][i] = ap[MS * i];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) b[0][j] = bp[32 * j];
+  for (int j = 0; j < TN; ++j) b[0][j] = bp[NS * j];
 #pragma unroll
   for (int s = 0; s < BK / 2; ++s) {
     const int cur = s & 1, nxt = cur ^ 1;
     if (s + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[nxt][i] = ap[2 * (s + 1) * LDA + 32 * i];
+      for (int i = 0; i < TM; ++i) a[nxt][i] = ap[2 * (s + 1) * LDA + MS * i];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[nxt][j] = bp[2 * (s + 1) * LDB + 32 * j];
+      for (int j = 0; j < TN; ++j) b[nxt][j] = bp[2 * (s + 1) * LDB + NS * j];
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -227,21 +231,21 @@ __device__ __forceinline__ void staged_epilogue(const f32x16 (&acc)[BM / WM / 32
   constexpr int V = BN / 4;                     // float4 per row
   constexpr int PER = WM * 32 * V / 256;        // float4 per thread per pass
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn0 = (wave % WN) * (BN / WN);
+  const int wm = wave / WN, wn0 = (wave % WN) * 32;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     __syncthreads();  // LDS is free: K loop / previous pass finished
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) smem[(wm * 32 + acc_row(e, lane)) * BN + wn0 + 32 * j + (lane & 31)] = acc[i][j][e];
+      for (int e = 0; e < 16; ++e) smem[(wm * 32 + acc_row(e, lane)) * BN + wn0 + 32 * WN * j + (lane & 31)] = acc[i][j][e];
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int idx = tid + 256 * q;
       const int lr = idx / V, c4 = idx - lr * V;
       const float4 v = *reinterpret_cast<const float4*>(smem + lr * BN + 4 * c4);
-      emit((lr >> 5) * (BM / WM) + 32 * i + (lr & 31), 4 * c4, v);
+      emit(32 * WM * i + lr, 4 * c4, v);  // staged row lr = 32 * wave_m + r  ->  tile row 32*WM*i + lr
     }
   }
 }
@@ -254,7 +258,7 @@ __device__ __forceinline__ void tile_colstats(float* __restrict__ smem, float (&
                                               float* __restrict__ bn_partial, int MT, int Cout, int mt, int nt, int tid) {
   constexpr int TN = BN / WN / 32;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn0 = (wave % WN) * (BN / WN);
+  const int wm = wave / WN, wn0 = (wave % WN) * 32;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {  // lanes l and l+32 hold the same column, different rows
     cs[j] += __shfl_xor(cs[j], 32, 64);
@@ -264,8 +268,8 @@ __device__ __forceinline__ void tile_colstats(float* __restrict__ smem, float (&
   if (lane < 32) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      smem[wm * BN + wn0 + 32 * j + lane] = cs[j];
-      smem[(WM + wm) * BN + wn0 + 32 * j + lane] = cq[j];
+      smem[wm * BN + wn0 + 32 * WN * j + lane] = cs[j];
+      smem[(WM + wm) * BN + wn0 + 32 * WN * j + lane] = cq[j];
     }
   }
   __syncthreads();
@@ -287,7 +291,7 @@ __device__ __forceinline__ void fprop_epilogue(const f32x16 (&acc)[BM / WM / 32]
                                                int mt, int nt, int tid) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WN) * (BM / WM);
+  const int wm0 = (wave / WN) * 32;
   staged_epilogue<BM, BN, WM, WN>(acc, smem, tid, [&](int tr, int tc, float4 v) {
     const int row = mt * BM + tr;
     if (row < g.M) *reinterpret_cast<float4*>(y + (size_t)row * g.Cout + nt * BN + tc) = v;
@@ -302,7 +306,7 @@ __device__ __forceinline__ void fprop_epilogue(const f32x16 (&acc)[BM / WM / 32]
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
+          const int row = mt * BM + wm0 + 32 * WM * i + acc_row(e, lane);
           const float v = row < g.M ? acc[i][j][e] : 0.f;
           cs[j] += v;
           cq[j] += v * v;
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_kernel(const float* __restr
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;  // tile i / j of the wave: + 32*WM*i / + 32*WN*j
   const int arow = tid >> 3, kg = tid & 7;
   const int HoWo = g.Ho * g.Wo;
   const int frame_bytes = g.H * g.W * g.Cin * 4;
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_kernel(const float* __restr
     store_transposed<LDB, BP>(Bs, rb, tid);
     __syncthreads();
     if (kt + 1 < it.ke) load();  // in flight during the MFMAs
-    mma_stage<LDA, LDB, TM, TN>(As, Bs, acc, wm0, wn0, lane);
+    mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN>(As, Bs, acc, wm0, wn0, lane);
   }
 
   if (it.pslot >= 0) {
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __re
   const int mt = tile / NT, nt = tile - mt * NT;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;  // tile i / j of the wave: + 32*WM*i / + 32*WN*j
   const int arow = tid >> 3, kg = tid & 7;
   const int HoWo = g.Ho * g.Wo;
   const int RS = g.R * g.S;
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __re
     store_transposed<LDB, BP>(Bs, rb, tid);
     __syncthreads();
     if (kt + 1 < nk) load(kt + 1);
-    mma_stage<LDA, LDB, TM, TN>(As, Bs, acc, wm0, wn0, lane);
+    mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN>(As, Bs, acc, wm0, wn0, lane);
   }
   fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, bn_partial, MT, mt, nt, tid);
 }
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
                                                           float* __restrict__ dx, const float* __restrict__ add_src,
                                                           const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk,
                                                           float* __restrict__ slab) {
-  constexpr int LDA = BM + 1, LDB = BN + 4;
+  constexpr int LDA = BM + 1, LDB = BN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
   constexpr int BV = BN / 4;
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;  // tile i / j of the wave: + 32*WM*i / + 32*WN*j
   const int arow = tid >> 3, kg = tid & 7;
   const int HcWc = Hc * Wc;
   const int HW = g.H * g.W;
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
       store_direct<LDB, BN, BP>(Bs, rb, tid);
       __syncthreads();
       if (kt + 1 < it.ke) load();
-      mma_stage<LDA, LDB, TM, TN>(As, Bs, acc, wm0, wn0, lane);
+      mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN>(As, Bs, acc, wm0, wn0, lane);
     }
   }
   if (it.pslot >= 0) {
@@ -698,11 +702,11 @@ struct BnFuse {
   float* dy_out;
 };
 
-template <int BM, int BN, int WM, int WN, bool C4, bool FBN>
+template <int BM, int BN, int WM, int WN, bool C4, bool FBN, bool INCR>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           float* __restrict__ slab, Geom g, int MTw, int NTw,
                                                           int kt_per_split, BnFuse bn) {
-  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int LDA = BM, LDB = BN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
   constexpr int AV = BM / 4, BV = BN / 4;
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
   const int mt = tile % MTw, nt = tile / MTw;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;  // tile i / j of the wave: + 32*WM*i / + 32*WN*j
   const int HoWo = g.Ho * g.Wo;
   const int frame_bytes = g.H * g.W * g.Cin * 4;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * frame_bytes, 0x00020000);
@@ -782,6 +786,33 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
   const int nkt_all = (g.M + BK - 1) / BK;
   const int kt_end = min(kt_begin + kt_per_split, nkt_all);
 
+  // INCR: the B rows of a thread advance by BK = 32 output pixels per K step, so the input position (hi, wi), the
+  // frame-in-clip index and the byte offset of the pixel are carried from step to step with two conditional wraps
+  // and additions only -- no division, modulo or integer multiply in the loop (the loader used to cost 325 VALU
+  // instructions per K step against 145 in fprop, and VALU issue is what holds the MFMA pipe of these kernels
+  // below 70 %).  The host selects INCR when a step spans less than one frame and at most Ho - 1 whole rows.
+  const int st = g.stride;
+  const int d_ho = BK / g.Wo, d_wo = BK - d_ho * g.Wo;
+  const int wrap_w = g.Wo * st, wrap_h = g.Ho * st;
+  const int px = g.Cin * 4;                                   // bytes per input pixel
+  const int inc0 = (d_ho * st * g.W + d_wo * st) * px;        // plain advance
+  const int inc1 = (st * g.W - wrap_w) * px;                  // extra when wo wraps into the next output row
+  const int inc2 = (g.H * g.W - wrap_h * g.W) * px;           // extra when ho wraps into the next frame
+  int s_hi[BP], s_wi[BP], s_t[BP], s_off[BP];
+  if (INCR) {
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+      const int m = split * kt_per_split * BK + b_krow[p];
+      const int n = m / HoWo;
+      const int rem = m - n * HoWo;
+      const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+      s_hi[p] = ho * st;
+      s_wi[p] = wo * st;
+      s_t[p] = n % g.T;
+      s_off[p] = ((n * g.H + s_hi[p]) * g.W + s_wi[p]) * px + b_off[p];
+    }
+  }
+
   float4 ra[AP], rb[BP];
   float4 ry[FBN ? AP : 1];
   uint32_t rm[FBN ? AP : 1];
@@ -800,21 +831,34 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
     for (int p = 0; p < BP; ++p) {
       const int m = m0 + b_krow[p];
       const bool mok = m < g.M;
-      int n, rem, ho, wo;
-      if (C4) {  // up to 2^23 pixels: exact integer division
+      int hi, wi, t, off;
+      if (INCR) {
+        hi = s_hi[p];
+        wi = s_wi[p];
+        t = s_t[p];
+        off = s_off[p];
+        const int w2 = wi + d_wo * st;
+        const bool c1 = w2 >= wrap_w;
+        s_wi[p] = c1 ? w2 - wrap_w : w2;
+        const int h2 = hi + d_ho * st + (c1 ? st : 0);
+        const bool c2 = h2 >= wrap_h;
+        s_hi[p] = c2 ? h2 - wrap_h : h2;
+        const int t2 = t + (c2 ? 1 : 0);
+        s_t[p] = t2 == g.T ? 0 : t2;
+        s_off[p] = off + inc0 + (c1 ? inc1 : 0) + (c2 ? inc2 : 0);
+      } else {  // exact integer divisions (tiny feature maps)
         const int mm = mok ? m : 0;
-        n = mm / HoWo;
-        rem = mm - n * HoWo;
-        ho = rem / g.Wo;
-        wo = rem - ho * g.Wo;
-      } else {
-        fast_divmod(mok ? m : 0, HoWo, g.rcp_HoWo, n, rem);
-        fast_divmod(rem, g.Wo, g.rcp_Wo, ho, wo);
+        const int n = mm / HoWo;
+        const int rem = mm - n * HoWo;
+        const int ho = rem / g.Wo;
+        hi = ho * st;
+        wi = (rem - ho * g.Wo) * st;
+        t = n % g.T;
+        off = ((n * g.H + hi) * g.W + wi) * px + b_off[p];
       }
-      const int hi = ho * g.stride, wi = wo * g.stride;
       const bool v = mok && b_cok[p] && (unsigned)(hi + b_r[p]) < (unsigned)g.H && (unsigned)(wi + b_s[p]) < (unsigned)g.W &&
-                     (unsigned)(n % g.T + b_cls[p]) < (unsigned)g.T;
-      rb[p] = buf_load16(xr, (((n * g.H + hi) * g.W + wi) * g.Cin * 4 + b_off[p]) | (v ? 0 : kOOB), 0);
+                     (unsigned)(t + b_cls[p]) < (unsigned)g.T;
+      rb[p] = buf_load16(xr, off | (v ? 0 : kOOB), 0);
     }
   };
 
@@ -844,7 +888,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
       store_direct<LDB, BN, BP>(Bs, rb, tid);
       __syncthreads();
       if (kt + 1 < kt_end) load(kt + 1);
-      mma_stage<LDA, LDB, TM, TN>(As, Bs, acc, wm0, wn0, lane);
+      mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN>(As, Bs, acc, wm0, wn0, lane);
     }
   }
 
@@ -854,19 +898,19 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
     int col;
     bool cok = true;
     if (C4) {
-      col = nt * BN + wn0 + 32 * j + (lane & 31);
+      col = nt * BN + wn0 + 32 * WN * j + (lane & 31);
       cok = col < g.Ktot;
     } else {
       const int per_tap = g.Cin / BN;
       const int tap = nt / per_tap;
-      col = tap * g.Cin + (nt - tap * per_tap) * BN + wn0 + 32 * j + (lane & 31);
+      col = tap * g.Cin + (nt - tap * per_tap) * BN + wn0 + 32 * WN * j + (lane & 31);
     }
     if (!cok) continue;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = mt * BM + wm0 + 32 * i + acc_row(e, lane);
+        const int row = mt * BM + wm0 + 32 * WM * i + acc_row(e, lane);
         out[(size_t)row * g.Ktot + col] = acc[i][j][e];
       }
   }
@@ -1051,7 +1095,7 @@ struct WgradPlan {
 };
 
 WgradPlan plan_wgrad(const bdv_conv_geom* g) {
-  const int W = 768;
+  static const int W = getenv("BDVCIL_WGRAD_W") ? atoi(getenv("BDVCIL_WGRAD_W")) : 768;
   WgradPlan p;
   p.c4 = (g->Cin % BK) != 0;
   p.small = p.c4 || (g->Cout % 128) != 0 || (g->Cin % 128) != 0;
@@ -1235,23 +1279,27 @@ extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float 
   if (debug_plan())
     fprintf(stderr, "[bdv plan] wgrad %dx%d Cin %d Cout %d k%d s%d: tiles %d -> splits %d x %d k-iters (%s)\n", gg->H, gg->W,
             gg->Cin, gg->Cout, gg->R, gg->stride, p.MTw * p.NTw, p.splits, p.kt_per_split, p.small ? "64x64" : "128x128");
+  const bool incr = g.Ho * g.Wo > BK && BK / g.Wo + 1 <= g.Ho;
+#define BDV_WGRAD(BMN, C4F, FBNF)                                                                                              \
+  do {                                                                                                                         \
+    if (incr)                                                                                                                  \
+      hipLaunchKernelGGL((conv_wgrad_kernel<BMN, BMN, 2, 2, C4F, FBNF, true>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw, \
+                         p.kt_per_split, bf);                                                                                  \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((conv_wgrad_kernel<BMN, BMN, 2, 2, C4F, FBNF, false>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw,    \
+                         p.NTw, p.kt_per_split, bf);                                                                           \
+  } while (0)
   if (bn != nullptr) {
-    if (!p.small)
-      hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false, true>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,
-                         p.kt_per_split, bf);
-    else
-      hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false, true>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,
-                         p.kt_per_split, bf);
+    if (!p.small) BDV_WGRAD(128, false, true);
+    else BDV_WGRAD(64, false, true);
   } else if (!p.small) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false, false>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,
-                       p.kt_per_split, bf);
+    BDV_WGRAD(128, false, false);
   } else if (p.c4) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true, false>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,
-                       p.kt_per_split, bf);
+    BDV_WGRAD(64, true, false);
   } else {
-    hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false, false>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,
-                       p.kt_per_split, bf);
+    BDV_WGRAD(64, false, false);
   }
+#undef BDV_WGRAD
   BDV_LAUNCH_CHECK("bdv_conv_wgrad");
   const int64_t numel4 = (int64_t)g.Cout * g.Ktot / 4;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((numel4 + 63) / 64)), dim3(256), 0, s, (const float*)slab, dw, beta, p.splits,
