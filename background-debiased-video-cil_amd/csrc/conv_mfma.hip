@@ -56,26 +56,36 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int
 // wave w owns rows 32w..32w+31 of every 32*WM-row group).  With an unpadded 128-float LDS row a tile pair is then 64
 // dwords apart and a K pair 256 dwords, which is what lets the compiler address all 32 operand reads of a stage as
 // ds_read2st64_b32 with immediate offsets from one base register instead of one v_add per read.
-template <int LDA, int LDB, int TM, int TN, int MS, int NS>
+// SWA / SWB: the operand image was written by store_transposed (K-contiguous source): unpadded 128-float rows with
+// the column XOR-ed by 4 * ((k >> 2) & 7), which spreads the transposing 4-byte stores over all banks without a row
+// pad.  The reader needs 8 base addresses per operand (one per swizzle value, registers) and again only immediates.
+template <int LDA, int LDB, int TM, int TN, int MS, int NS, bool SWA, bool SWB>
 __device__ __forceinline__ void mma_stage(const float* __restrict__ As, const float* __restrict__ Bs,
                                           f32x16 (&acc)[TM][TN], int wm0, int wn0, int lane) {
   const int r = lane & 31, h = lane >> 5;
-  const float* ap = As + h * LDA + wm0 + r;
-  const float* bp = Bs + h * LDB + wn0 + r;
+  const float* apv[SWA ? 8 : 1];
+  const float* bpv[SWB ? 8 : 1];
+#pragma unroll
+  for (int c = 0; c < (SWA ? 8 : 1); ++c) apv[c] = As + h * LDA + wm0 + (r ^ (4 * c));
+#pragma unroll
+  for (int c = 0; c < (SWB ? 8 : 1); ++c) bpv[c] = Bs + h * LDB + wn0 + (r ^ (4 * c));
+  // element [k = 2s + h][tile i]: swizzle value (k >> 2) & 7 = (s >> 1) & 7
+  auto ap = [&](int s, int i) { return apv[SWA ? ((s >> 1) & 7) : 0][2 * s * LDA + MS * i]; };
+  auto bp = [&](int s, int j) { return bpv[SWB ? ((s >> 1) & 7) : 0][2 * s * LDB + NS * j]; };
   // operand fragments are fetched one K-pair ahead of the MFMAs that consume them
   float a[2][TM], b[2][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) a[0][i] = ap[MS * i];
+  for (int i = 0; i < TM; ++i) a[0][i] = ap(0, i);
 #pragma unroll
-  for (int j = 0; j < TN; ++j) b[0][j] = bp[NS * j];
+  for (int j = 0; j < TN; ++j) b[0][j] = bp(0, j);
 #pragma unroll
   for (int s = 0; s < BK / 2; ++s) {
     const int cur = s & 1, nxt = cur ^ 1;
     if (s + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[nxt][i] = ap[2 * (s + 1) * LDA + MS * i];
+      for (int i = 0; i < TM; ++i) a[nxt][i] = ap(s + 1, i);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[nxt][j] = bp[2 * (s + 1) * LDB + NS * j];
+      for (int j = 0; j < TN; ++j) b[nxt][j] = bp(s + 1, j);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -94,13 +104,15 @@ __device__ __forceinline__ int shift_class(int c, int fold) {
   return (fold > 0) ? (c < fold ? 1 : (c < 2 * fold ? -1 : 0)) : 0;
 }
 
-// K-contiguous source tile (ROWS x 32 k, thread = (row tid/8, 16-byte group tid%8)) -> transposing store
+// K-contiguous source tile (ROWS x 32 k, thread = (row tid/8, 16-byte group kg = tid%8)) -> transposing store into the
+// k-major image with unpadded rows of LD floats; column ^ (4 * kg) (kg = k >> 2) makes the 32 lanes of a store
+// (4 rows x 8 kg) hit 32 different banks.
 template <int LD, int PASSES>
 __device__ __forceinline__ void store_transposed(float* __restrict__ dst, const float4 (&v)[PASSES], int tid) {
   const int row = tid >> 3, kg = tid & 7;
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
-    float* d = dst + (4 * kg) * LD + row + 32 * p;
+    float* d = dst + (4 * kg) * LD + ((row + 32 * p) ^ (4 * kg));
     d[0] = v[p].x;
     d[LD] = v[p].y;
     d[2 * LD] = v[p].z;
@@ -324,7 +336,7 @@ template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 3) void conv_fprop_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           float* __restrict__ y, Geom g, int NT, Work wk,
                                                           float* __restrict__ slab, float* __restrict__ bn_partial, int MT) {
-  constexpr int LDA = BM + 1, LDB = BN + 1;
+  constexpr int LDA = BM, LDB = BN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
   __shared__ __attribute__((aligned(16))) float smem[BK * (LDA + LDB)];
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_kernel(const float* __restr
     store_transposed<LDB, BP>(Bs, rb, tid);
     __syncthreads();
     if (kt + 1 < it.ke) load();  // in flight during the MFMAs
-    mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN>(As, Bs, acc, wm0, wn0, lane);
+    mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN, true, true>(As, Bs, acc, wm0, wn0, lane);
   }
 
   if (it.pslot >= 0) {
@@ -422,7 +434,7 @@ template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              float* __restrict__ y, Geom g, int NT, float* __restrict__ bn_partial,
                                                              int MT) {
-  constexpr int LDA = BM + 1, LDB = BN + 1;
+  constexpr int LDA = BM, LDB = BN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
   __shared__ __attribute__((aligned(16))) float smem[BK * (LDA + LDB)];
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __re
     store_transposed<LDB, BP>(Bs, rb, tid);
     __syncthreads();
     if (kt + 1 < nk) load(kt + 1);
-    mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN>(As, Bs, acc, wm0, wn0, lane);
+    mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN, true, true>(As, Bs, acc, wm0, wn0, lane);
   }
   fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, bn_partial, MT, mt, nt, tid);
 }
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
                                                           float* __restrict__ dx, const float* __restrict__ add_src,
                                                           const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk,
                                                           float* __restrict__ slab) {
-  constexpr int LDA = BM + 1, LDB = BN;
+  constexpr int LDA = BM, LDB = BN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
   constexpr int BV = BN / 4;
@@ -632,7 +644,7 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
       store_direct<LDB, BN, BP>(Bs, rb, tid);
       __syncthreads();
       if (kt + 1 < it.ke) load();
-      mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN>(As, Bs, acc, wm0, wn0, lane);
+      mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN, true, false>(As, Bs, acc, wm0, wn0, lane);
     }
   }
   if (it.pslot >= 0) {
@@ -888,7 +900,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
       store_direct<LDB, BN, BP>(Bs, rb, tid);
       __syncthreads();
       if (kt + 1 < kt_end) load(kt + 1);
-      mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN>(As, Bs, acc, wm0, wn0, lane);
+      mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN, false, false>(As, Bs, acc, wm0, wn0, lane);
     }
   }
 
