@@ -1,0 +1,128 @@
+// Microbenchmark of the current conv main loop (BK = 32, one LDS stage, XOR-swizzled unpadded k-major image, operand
+// reads with immediate offsets) as a plain GEMM, for different block / wave tile shapes.  Both operands K-contiguous.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BK = 32;
+
+template <int LDA, int LDB, int TM, int TN, int MS, int NS>
+__device__ __forceinline__ void mma_stage(const float* __restrict__ As, const float* __restrict__ Bs, f32x16 (&acc)[TM][TN], int wm0, int wn0, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const float* apv[8];
+  const float* bpv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) apv[c] = As + h * LDA + wm0 + (r ^ (4 * c));
+#pragma unroll
+  for (int c = 0; c < 8; ++c) bpv[c] = Bs + h * LDB + wn0 + (r ^ (4 * c));
+  auto ap = [&](int s, int i) { return apv[(s >> 1) & 7][2 * s * LDA + MS * i]; };
+  auto bp = [&](int s, int j) { return bpv[(s >> 1) & 7][2 * s * LDB + NS * j]; };
+  float a[2][TM], b[2][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a[0][i] = ap(0, i);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b[0][j] = bp(0, j);
+#pragma unroll
+  for (int s = 0; s < BK / 2; ++s) {
+    const int cur = s & 1, nxt = cur ^ 1;
+    if (s + 1 < BK / 2) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[nxt][i] = ap(s + 1, i);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[nxt][j] = bp(s + 1, j);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+  }
+}
+
+template <int LD, int PASSES>
+__device__ __forceinline__ void store_transposed(float* __restrict__ dst, const float4 (&v)[PASSES], int tid) {
+  const int row = tid >> 3, kg = tid & 7;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    float* d = dst + (4 * kg) * LD + ((row + 32 * p) ^ (4 * kg));
+    d[0] = v[p].x; d[LD] = v[p].y; d[2 * LD] = v[p].z; d[3 * LD] = v[p].w;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int MINB>
+__global__ __launch_bounds__(256, MINB) void kg(const float* __restrict__ A, const float* __restrict__ B, float* out, int iters, int ld) {
+  constexpr int AP = BM / 32, BP = BN / 32;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  __shared__ __attribute__((aligned(16))) float smem[BK * (BM + BN)];
+  float* const As = smem;
+  float* const Bs = smem + BK * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;
+  const int arow = tid >> 3, kg_ = tid & 7;
+  const float* ap = A + (size_t)(blockIdx.x % 128) * BM * ld + (size_t)arow * ld + 4 * kg_;
+  const float* bp = B + (size_t)(blockIdx.x % 4) * BN * ld + (size_t)arow * ld + 4 * kg_;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float4 ra[AP], rb[BP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) ra[p] = *reinterpret_cast<const float4*>(ap + (size_t)p * 32 * ld);
+#pragma unroll
+  for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const float4*>(bp + (size_t)p * 32 * ld);
+  for (int kt = 0; kt < iters; ++kt) {
+    __syncthreads();
+    store_transposed<BM, AP>(As, ra, tid);
+    store_transposed<BN, BP>(Bs, rb, tid);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < AP; ++p) ra[p] = *reinterpret_cast<const float4*>(ap + (kt + 1) * BK + (size_t)p * 32 * ld);
+#pragma unroll
+    for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const float4*>(bp + (kt + 1) * BK + (size_t)p * 32 * ld);
+    mma_stage<BM, BN, TM, TN, 32 * WM, 32 * WN>(As, Bs, acc, wm0, wn0, lane);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+  out[(size_t)blockIdx.x * 256 + tid] = s;
+}
+
+template <int BM, int BN, int WM, int WN, int MINB>
+void run(const char* name, int K, float* A, float* B, float* d, int ld) {
+  auto kern = kg<BM, BN, WM, WN, MINB>;
+  const int iters = K / BK;
+  for (int mult : {1, 2, 3, 4, 6, 12}) {
+    const int blocks = 256 * mult;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, A, B, d, iters, ld); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, A, B, d, iters, ld);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    double flops = (double)blocks * K * BM * BN * 2.0;
+    printf("%-36s blocks %5d: %.3f ms  %.1f TFLOP/s\n", name, blocks, ms, flops / ms / 1e9);
+  }
+}
+
+int main() {
+  const int K = 2304, ld = K + 64;
+  float *A, *B, *d;
+  size_t na = (size_t)128 * 256 * ld + 4096, nb = (size_t)4 * 256 * ld + 4096;
+  hipMalloc(&A, na * 4); hipMalloc(&B, nb * 4); hipMalloc(&d, (size_t)4096 * 512 * 4);
+  float* h = (float*)malloc(na * 4);
+  for (size_t i = 0; i < na; ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
+  hipMemcpy(A, h, na * 4, hipMemcpyHostToDevice); hipMemcpy(B, h, nb * 4, hipMemcpyHostToDevice);
+  run<128, 128, 2, 2, 3>("128x128 wave 64x64, 3 blocks/CU", K, A, B, d, ld);
+  run<256, 128, 2, 2, 2>("256x128 wave 128x64, 2 blocks/CU", K, A, B, d, ld);
+  run<128, 256, 2, 2, 2>("128x256 wave 64x128, 2 blocks/CU", K, A, B, d, ld);
+  run<256, 128, 2, 2, 1>("256x128 wave 128x64, regs for 1", K, A, B, d, ld);
+  return 0;
+}
