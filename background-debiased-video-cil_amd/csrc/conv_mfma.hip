@@ -4,18 +4,20 @@
 // Replaces: F.conv2d + autograd inside UPSTREAM mmaction ConvModule, and UPSTREAM
 // TemporalShift.shift (fused into the activation-tile gather).
 //
-// Structure of every kernel (chosen with tools/ubench/gemm_variants.hip: 124-130 TFLOP/s at any grid size,
-// vs 97-122 for a 16-deep double-buffered loop):
-//   * 256 threads = 4 waves; block tile BM x BN; K-step 32; wave tile = 2x2 / 2x1 MFMA 32x32 tiles;
-//   * ONE LDS stage: K-major image ([k][m]) of both operands, so one MFMA operand is one conflict-free
-//     ds_read_b32 (lane l reads [k = 2s + l/32][m = base + l%32]); operand fragments are fetched one K-pair
-//     ahead of the MFMAs (order pinned with sched_group_barrier);
+// Structure of every kernel (tools/ubench/gemm_v2.hip is this loop as a plain GEMM):
+//   * 256 threads = 4 waves; block tile BM x BN; K-step 32; wave tile = 2x2 / 2x1 MFMA 32x32 tiles, the tiles of a
+//     wave interleaved with those of the other wave (wave w: rows 32w..32w+31 of every 64-row group);
+//   * ONE LDS stage: K-major image ([k][m]) of both operands in unpadded rows, so one MFMA operand is one
+//     conflict-free ds_read_b32 (lane l reads [k = 2s + l/32][m = base + l%32]) and every read of a stage has an
+//     immediate offset (ds_read2st64_b32); fragments are fetched one K-pair ahead of the MFMAs that use them;
 //   * register-staged global loads, issued right after the stage is published and consumed after the MFMAs:
 //     barrier, store registers -> LDS, barrier, issue next loads, 64 MFMAs;
-//   * K-contiguous operands are read as full 128-byte lines (8 lanes x 16 B per row) and stored transposed
-//     (row stride BM+1: the 8x4 lane pattern hits 32 distinct banks); M-contiguous operands are stored with
-//     16-byte writes (row stride BM+4);
+//   * K-contiguous operands are read as full 128-byte lines (8 lanes x 16 B per row) and stored transposed with an
+//     XOR swizzle of the column (store_transposed); M-contiguous operands are stored with 16-byte writes;
 //   * halo / clip-end / ragged lanes use buffer loads with an out-of-range offset (hardware returns zeros).
+// The kernels are bound by instruction issue (a 32x32x2 fp32 MFMA holds its SIMD for 64 cycles and every other
+// instruction adds its issue cycles: utilisation ~ 64 / (64 + 4 * VALU-per-MFMA + 10)), hence the emphasis on
+// address arithmetic that folds into immediates or is carried incrementally.
 #include <stdlib.h>
 #include "common.h"
 
