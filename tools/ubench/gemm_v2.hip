@@ -40,6 +40,42 @@ __device__ __forceinline__ void mma_stage(const float* __restrict__ As, const fl
   }
 }
 
+// Row-pair variant: tile i of a wave = rows 2r + i of its 64-row group, so both tiles' operands are one 8-byte read.
+template <int LDA, int LDB>
+__device__ __forceinline__ void mma_stage_pair(const float* __restrict__ As, const float* __restrict__ Bs, f32x16 (&acc)[2][2], int wm0, int wn0, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const float* apv[8];
+  const float* bpv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) apv[c] = As + h * LDA + wm0 + ((2 * r) ^ (4 * c));
+#pragma unroll
+  for (int c = 0; c < 8; ++c) bpv[c] = Bs + h * LDB + wn0 + ((2 * r) ^ (4 * c));
+  auto ap = [&](int s) { return *reinterpret_cast<const float2*>(apv[(s >> 1) & 7] + 2 * s * LDA); };
+  auto bp = [&](int s) { return *reinterpret_cast<const float2*>(bpv[(s >> 1) & 7] + 2 * s * LDB); };
+  // fragments for two K pairs at a time: the two 8-byte reads of an operand share a base and merge into one
+  // ds_read2st64_b64
+  float2 a[2][2], b[2][2];
+  a[0][0] = ap(0); a[0][1] = ap(1);
+  b[0][0] = bp(0); b[0][1] = bp(1);
+#pragma unroll
+  for (int sp = 0; sp < BK / 4; ++sp) {
+    const int cur = sp & 1, nxt = cur ^ 1;
+    if (sp + 1 < BK / 4) {
+      a[nxt][0] = ap(2 * sp + 2); a[nxt][1] = ap(2 * sp + 3);
+      b[nxt][0] = bp(2 * sp + 2); b[nxt][1] = bp(2 * sp + 3);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][q].x, b[cur][q].x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][q].x, b[cur][q].y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][q].y, b[cur][q].x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][q].y, b[cur][q].y, acc[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+  }
+}
+
 template <int LD, int PASSES>
 __device__ __forceinline__ void store_transposed(float* __restrict__ dst, const float4 (&v)[PASSES], int tid) {
   const int row = tid >> 3, kg = tid & 7;
@@ -50,7 +86,7 @@ __device__ __forceinline__ void store_transposed(float* __restrict__ dst, const 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int MINB>
+template <int BM, int BN, int WM, int WN, int MINB, bool PAIR = false>
 __global__ __launch_bounds__(256, MINB) void kg(const float* __restrict__ A, const float* __restrict__ B, float* out, int iters, int ld) {
   constexpr int AP = BM / 32, BP = BN / 32;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -83,7 +119,8 @@ __global__ __launch_bounds__(256, MINB) void kg(const float* __restrict__ A, con
     for (int p = 0; p < AP; ++p) ra[p] = *reinterpret_cast<const float4*>(ap + (kt + 1) * BK + (size_t)p * 32 * ld);
 #pragma unroll
     for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const float4*>(bp + (kt + 1) * BK + (size_t)p * 32 * ld);
-    mma_stage<BM, BN, TM, TN, 32 * WM, 32 * WN>(As, Bs, acc, wm0, wn0, lane);
+    if constexpr (PAIR) mma_stage_pair<BM, BN>(As, Bs, acc, (wave / WN) * 64, (wave % WN) * 64, lane);
+    else mma_stage<BM, BN, TM, TN, 32 * WM, 32 * WN>(As, Bs, acc, wm0, wn0, lane);
   }
   float s = 0.f;
 #pragma unroll
@@ -95,9 +132,9 @@ __global__ __launch_bounds__(256, MINB) void kg(const float* __restrict__ A, con
   out[(size_t)blockIdx.x * 256 + tid] = s;
 }
 
-template <int BM, int BN, int WM, int WN, int MINB>
+template <int BM, int BN, int WM, int WN, int MINB, bool PAIR = false>
 void run(const char* name, int K, float* A, float* B, float* d, int ld) {
-  auto kern = kg<BM, BN, WM, WN, MINB>;
+  auto kern = kg<BM, BN, WM, WN, MINB, PAIR>;
   const int iters = K / BK;
   for (int mult : {1, 2, 3, 4, 6, 12}) {
     const int blocks = 256 * mult;
@@ -121,6 +158,7 @@ int main() {
   for (size_t i = 0; i < na; ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
   hipMemcpy(A, h, na * 4, hipMemcpyHostToDevice); hipMemcpy(B, h, nb * 4, hipMemcpyHostToDevice);
   run<128, 128, 2, 2, 3>("128x128 wave 64x64, 3 blocks/CU", K, A, B, d, ld);
+  run<128, 128, 2, 2, 3, true>("128x128 row-pair b64 reads", K, A, B, d, ld);
   run<256, 128, 2, 2, 2>("256x128 wave 128x64, 2 blocks/CU", K, A, B, d, ld);
   run<128, 256, 2, 2, 2>("128x256 wave 64x128, 2 blocks/CU", K, A, B, d, ld);
   run<256, 128, 2, 2, 1>("256x128 wave 128x64, regs for 1", K, A, B, d, ld);
