@@ -25,6 +25,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 R50_FLOP_PER_CLIP = 194.29e9       # BASELINE.md section 2 (fwd+bwd, conv MACs only, stem dgrad excluded)
+R50_KD_FLOP_PER_CLIP = 259.7e9     # + the frozen previous model's forward
 PEAK_F32_MFMA = 157.3e12           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 
 
@@ -150,6 +151,9 @@ def main():
     ap.add_argument('--head', default='SimpleLinear', choices=['SimpleLinear', 'LocalSimilarityClassifier'])
     ap.add_argument('--loss', default='CrossEntropyLoss', choices=['CrossEntropyLoss', 'LSCLoss'])
     ap.add_argument('--dropout', type=float, default=0.5)
+    ap.add_argument('--workload', default='ce', choices=['ce', 'cil'],
+                    help="'ce': BASELINE config 2 (the metric); 'cil': config 3 step = uint8 background-mix front-end, LSC head + "
+                         "LSCLoss, feature-KD against a frozen previous model (task >= 1), clip 1.0, SGD")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -174,6 +178,9 @@ def main():
     if not args.no_kernel_timing:
         timer.wrap(K)
 
+    cil = args.workload == 'cil'
+    if cil:
+        args.head, args.loss = 'LocalSimilarityClassifier', 'LSCLoss'
     torch.manual_seed(0)
     model = bd.build_model(model_cfg(args.depth, args.classes, args.head, args.loss, args.dropout)).to(dev)
     model.train()
@@ -183,12 +190,35 @@ def main():
         reducer = bd.GradAllReducer(model, bucket_cap_mb=25.0)
     opt = bd.build_optimizer(model, dict(type='SGD', constructor='CILTSMOptimizerConstructorImprovised',
                                          paramwise_cfg=dict(fc_lr_scale_factor=5.0), lr=0.01, momentum=0.9, weight_decay=1e-4))
-    engine = bd.TrainEngine(model, opt, grad_clip=None, reducer=reducer)
+    engine = bd.TrainEngine(model, opt, grad_clip=1.0 if cil else None, reducer=reducer)
 
     g = torch.Generator().manual_seed(1000 + rank)
-    imgs = torch.randn(args.batch, 8, 3, 224, 224, generator=g).to(dev)
     labels = torch.randint(0, args.classes, (args.batch, 1), generator=g).to(dev)
-    batch = dict(imgs=imgs, label=labels)
+    loss_fn = None
+    if cil:
+        # uint8 frames + background + mix mask -> fused front-end; teacher = same
+        # architecture (seed 1); KD modules / weights / scale of configs/ucf101/bgmix_plus_randAug/...py:88-89
+        frames = torch.randint(0, 256, (args.batch, 8, 224, 224, 3), generator=g, dtype=torch.uint8).to(dev)
+        bg = torch.randint(0, 256, (args.batch, 224, 224, 3), generator=g, dtype=torch.uint8).to(dev)
+        mix = (torch.rand(args.batch, generator=torch.Generator().manual_seed(1)) < 0.25).to(dev)
+        torch.manual_seed(1)
+        prev = bd.build_model(model_cfg(args.depth, args.classes, args.head, args.loss, args.dropout)).to(dev)
+        prev.eval()
+        for q in prev.parameters():
+            q.requires_grad_(False)
+        names = ['backbone.layer1', 'backbone.layer2', 'backbone.layer3', 'backbone.layer4', 'cls_head.avg_pool']
+        cur_hooks, prev_hooks = bd.OutputHook(model, names), bd.OutputHook(prev, names)
+        front = bd.BackgroundMixFrontEnd(alpha=0.5)
+        batch = dict(frames=frames, bg=bg, mix=mix, label=labels)
+
+        def loss_fn(m, b):
+            data = dict(imgs=front(b['frames'], b['bg'], b['mix']), label=b['label'])
+            return bd.base_training_step(m, data, current_task=1, prev_model=prev, current_hooks=cur_hooks,
+                                         prev_hooks=prev_hooks, kd_modules_names=names, kd_weight_by_module=[0.01] * 5,
+                                         adaptive_scale_factors=[1.0, 3.3466401061363023])
+    else:
+        imgs = torch.randn(args.batch, 8, 3, 224, 224, generator=g).to(dev)
+        batch = dict(imgs=imgs, label=labels)
 
     def sync():
         if world > 1:
@@ -196,13 +226,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        engine.step(batch)
+        engine.step(batch, loss_fn)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         # per-kernel HIP events on every 4th timed step: the ~640 extra event records per step cost 2 % otherwise
         timer.enabled = (not args.no_kernel_timing) and i % 4 == 0
-        out = engine.step(batch)
+        out = engine.step(batch, loss_fn)
     sync()
     dt = time.perf_counter() - t0
     timer.enabled = False
@@ -215,13 +245,15 @@ def main():
     if rank == 0:
         clips = args.batch * world * args.steps
         value = clips / dt
-        flop_per_clip = R50_FLOP_PER_CLIP if args.depth == 50 else None
+        flop_per_clip = (R50_KD_FLOP_PER_CLIP if cil else R50_FLOP_PER_CLIP) if args.depth == 50 else None
         res = {
-            'metric': 'clips/sec fwd+bwd TSM-R50 8x224^2 bs32/GPU' if args.depth == 50 else f'clips/sec fwd+bwd TSM-R{args.depth}',
+            'metric': ('clips/sec fwd+bwd TSM-R50 8x224^2 bs32/GPU' if args.depth == 50 else f'clips/sec fwd+bwd TSM-R{args.depth}')
+                      + (' (CIL step: bg-mix front-end + KD teacher + LSCLoss)' if cil else ''),
             'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000.0 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'TSM-ResNet{args.depth} fwd+bwd+SGD step, synthetic {args.batch}x8x3x224x224 clips per GPU, '
+            'config': {'workload': ('CIL task-1 step (uint8 bg-mix front-end, frozen teacher forward, 5 feature-KD MSE terms, clip 1.0): ' if cil else '')
+                                   + f'TSM-ResNet{args.depth} fwd+bwd+SGD step, synthetic {args.batch}x8x3x224x224 clips per GPU, '
                                    f'{args.classes} classes, {args.head}+{args.loss}, dropout {args.dropout}, random-init weights',
                        'clips_per_gpu': args.batch, 'global_batch': args.batch * world, 'parallelism': f'dp{world}',
                        'final_loss': round(loss_val, 5)},
@@ -251,7 +283,7 @@ def main():
                 'conv_ms_per_step': round(tot_ms / timed_steps, 3), 'conv_tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                 'kernel_timed_steps': timed_steps,
             }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not cil:
             res['cpu_baseline'] = cpu_baseline(args.depth, args.classes, args.head, args.loss)
         print(json.dumps(res), flush=True)
     if world > 1:
