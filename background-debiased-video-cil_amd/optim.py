@@ -23,6 +23,12 @@ from .losses import LSCLoss
 from .registry import OPTIMIZER_BUILDERS, build_from_cfg
 
 
+def _same_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """Same element order in memory: strides agree on every dimension longer than 1 (a 1x1 conv weight in
+    channels_last order and its plainly contiguous parameter differ only in the strides of the size-1 dims)."""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+
+
 class FusedSGD(torch.optim.Optimizer):
     def __init__(self, params, lr=0.01, momentum=0.0, weight_decay=0.0, dampening=0, nesterov=False):
         if dampening != 0 or nesterov:
@@ -51,7 +57,7 @@ class FusedSGD(torch.optim.Optimizer):
             g = p.grad
             if g.dtype != torch.float32 or p.dtype != torch.float32:
                 raise TypeError('FusedSGD: fp32 only')
-            if g.stride() != p.stride() or not K._dense_storage(p).is_contiguous():
+            if not _same_layout(g, p) or not K._dense_storage(p).is_contiguous():
                 p.grad = torch.empty_like(p).copy_(g)          # rare: make the layouts agree
             st = self.state[p]
             if 'momentum_buffer' not in st:
