@@ -9,60 +9,88 @@ namespace {
 constexpr float COS_EPS = 1e-8f;  // F.cosine_similarity default eps
 
 // ---------------------------------------------------------------------------------------
-// dot[n][j] = <x_n, w_j>  (+ optional norms), grid = N blocks, x_n staged in LDS
-// MODE 0: linear (out = dot + bias); MODE 1: LSC (cos + proxy reduction)
+// dot[n][j] = <x_n, w_j>  (+ optional norms).  A block stages RB rows of x in LDS so that every w row it streams from
+// L2 is used RB times (the one-row version re-read all of w per row: 212 MB of L2 traffic for 256 x 2048 x 101).
+// MODE 0: linear (out = dot + bias); MODE 1: LSC (cos + proxy reduction).  Per (n, j) the summation order is the same
+// for every RB.
 // ---------------------------------------------------------------------------------------
+constexpr int HEAD_RB = 4;
+
 template <int MODE>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         float* __restrict__ xnorm, float* __restrict__ wnorm,
                                                         float* __restrict__ cosbuf, int N, int D, int K, int P) {
+  constexpr int RB = HEAD_RB;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* xs = sm;            // D
-  float* cs = sm + D;        // K*P
-  __shared__ float red[4];
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* xs = sm;               // RB x D
+  float* cs = sm + RB * D;      // RB x K*P
+  __shared__ float red[RB][4];
+  const int n0 = blockIdx.x * RB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int KP = K * P;
-  float ss = 0.f;
-  for (int d = tid; d < D; d += 256) {
-    const float v = x[(size_t)n * D + d];
-    xs[d] = v;
-    ss += v * v;
+  const int rows = min(RB, N - n0);
+  float ss[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    ss[r] = 0.f;
+    if (r < rows)
+      for (int d = tid; d < D; d += 256) {
+        const float v = x[(size_t)(n0 + r) * D + d];
+        xs[r * D + d] = v;
+        ss[r] += v * v;
+      }
+    else
+      for (int d = tid; d < D; d += 256) xs[r * D + d] = 0.f;
+    ss[r] = wave_sum(ss[r]);
+    if (lane == 0) red[r][wave] = ss[r];
   }
-  ss = wave_sum(ss);
-  if (lane == 0) red[wave] = ss;
   __syncthreads();
-  float nx = 1.f;
-  if (MODE == 1) {
-    nx = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), COS_EPS);
-    if (tid == 0) xnorm[n] = nx;
+  float nx[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    nx[r] = 1.f;
+    if (MODE == 1) {
+      nx[r] = fmaxf(sqrtf(red[r][0] + red[r][1] + red[r][2] + red[r][3]), COS_EPS);
+      if (tid == 0 && r < rows) xnorm[n0 + r] = nx[r];
+    }
   }
   for (int j = wave; j < KP; j += 4) {
     const float* wr = w + (size_t)j * D;
-    float dot = 0.f, wq = 0.f;
+    float dot[RB], wq = 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) dot[r] = 0.f;
     for (int d = lane; d < D; d += 64) {
       const float wv = wr[d];
-      dot += xs[d] * wv;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) dot[r] += xs[r * D + d] * wv;
       if (MODE == 1) wq += wv * wv;
     }
-    dot = wave_sum(dot);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) dot[r] = wave_sum(dot[r]);
     if (MODE == 1) {
       wq = wave_sum(wq);
       const float nw = fmaxf(sqrtf(wq), COS_EPS);
-      const float c = dot / (nx * nw);
       if (lane == 0) {
-        cs[j] = c;
-        cosbuf[(size_t)n * KP + j] = c;
-        if (n == 0) wnorm[j] = nw;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          if (r < rows) {
+            const float c = dot[r] / (nx[r] * nw);
+            cs[r * KP + j] = c;
+            cosbuf[(size_t)(n0 + r) * KP + j] = c;
+          }
+        if (n0 == 0) wnorm[j] = nw;
       }
     } else if (lane == 0) {
-      out[(size_t)n * K + j] = dot + (bias != nullptr ? bias[j] : 0.f);
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+        if (r < rows) out[(size_t)(n0 + r) * K + j] = dot[r] + (bias != nullptr ? bias[j] : 0.f);
     }
   }
   if (MODE == 1) {
     __syncthreads();
-    for (int k = tid; k < K; k += 256) {
-      const float* c = cs + k * P;
+    for (int q = tid; q < rows * K; q += 256) {
+      const int r = q / K, k = q - r * K;
+      const float* c = cs + r * KP + k * P;
       float mx = c[0];
       for (int p = 1; p < P; ++p) mx = fmaxf(mx, c[p]);
       float den = 0.f, num = 0.f;
@@ -71,7 +99,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         den += e;
         num += e * c[p];
       }
-      out[(size_t)n * K + k] = num / den;
+      out[(size_t)(n0 + r) * K + k] = num / den;
     }
   }
 }
@@ -152,35 +180,63 @@ __global__ __launch_bounds__(256) void lsc_bwd_dw_kernel(const float* __restrict
 // linear backward: dx[n,:] = sum_k dout[n,k] w_k   (grid N)
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ dout, const float* __restrict__ w,
                                                              float* __restrict__ dx, int N, int D, int K) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int n = blockIdx.x, tid = threadIdx.x;
-  for (int k = tid; k < K; k += 256) sm[k] = dout[(size_t)n * K + k];
+  constexpr int RB = HEAD_RB;  // rows per block: each w element loaded once per RB rows
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // RB x K
+  const int n0 = blockIdx.x * RB, tid = threadIdx.x;
+  const int rows = min(RB, N - n0);
+  for (int q = tid; q < RB * K; q += 256) {
+    const int r = q / K, k = q - r * K;
+    sm[q] = r < rows ? dout[(size_t)(n0 + r) * K + k] : 0.f;
+  }
   __syncthreads();
   for (int d = tid; d < D; d += 256) {
-    float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc += sm[k] * w[(size_t)k * D + d];
-    dx[(size_t)n * D + d] = acc;
+    float acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float wv = w[(size_t)k * D + d];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) acc[r] += sm[r * K + k] * wv;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+      if (r < rows) dx[(size_t)(n0 + r) * D + d] = acc[r];
   }
 }
 
-// linear backward: dw[k,:] = beta*dw + sum_n dout[n,k] x_n ; db[k] = beta*db + sum_n dout[n,k]   (grid K)
 __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ dout, const float* __restrict__ x,
                                                              float* __restrict__ dw, float* __restrict__ db, float beta, int N, int D,
                                                              int K) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int k = blockIdx.x, tid = threadIdx.x;
-  for (int n = tid; n < N; n += 256) sm[n] = dout[(size_t)n * K + k];
-  __syncthreads();
-  for (int d = tid; d < D; d += 256) {
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) acc += sm[n] * x[(size_t)n * D + d];
-    if (beta != 0.f) acc += beta * dw[(size_t)k * D + d];
-    dw[(size_t)k * D + d] = acc;
+  constexpr int KB = 8;  // classes per block: each x element loaded once per KB classes; grid = (ceil(K/KB), ceil(D/256))
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // N x KB
+  const int k0 = blockIdx.x * KB, tid = threadIdx.x, d = blockIdx.y * 256 + tid;
+  const int ks = min(KB, K - k0);
+  for (int q = tid; q < N * KB; q += 256) {
+    const int n = q / KB, kk = q - n * KB;
+    sm[q] = kk < ks ? dout[(size_t)n * K + k0 + kk] : 0.f;
   }
-  if (db != nullptr && tid == 0) {
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += sm[n];
-    db[k] = (beta != 0.f ? beta * db[k] : 0.f) + s;
+  __syncthreads();
+  if (d < D) {
+    float acc[KB];
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) acc[kk] = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float xv = x[(size_t)n * D + d];
+#pragma unroll
+      for (int kk = 0; kk < KB; ++kk) acc[kk] += sm[n * KB + kk] * xv;
+    }
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk)
+      if (kk < ks) {
+        float v = acc[kk];
+        if (beta != 0.f) v += beta * dw[(size_t)(k0 + kk) * D + d];
+        dw[(size_t)(k0 + kk) * D + d] = v;
+      }
+  }
+  if (db != nullptr && blockIdx.y == 0 && tid < ks) {
+    float t = 0.f;
+    for (int n = 0; n < N; ++n) t += sm[n * KB + tid];
+    db[k0 + tid] = (beta != 0.f ? beta * db[k0 + tid] : 0.f) + t;
   }
 }
 
@@ -430,9 +486,9 @@ __global__ __launch_bounds__(256) void kd_mse_bwd_kernel(const float4* __restric
 extern "C" int bdv_lsc_fwd(const float* x, const float* w, float* sim, float* xnorm, float* wnorm, float* cosbuf, int N, int D,
                            int K, int P, void* stream) {
   BDV_REQUIRE(x && w && sim && xnorm && wnorm && cosbuf && N > 0 && D > 0 && K > 0 && P > 0, "bdv_lsc_fwd: bad argument");
-  const size_t lds = (size_t)(D + K * P) * sizeof(float);
+  const size_t lds = (size_t)HEAD_RB * (D + K * P) * sizeof(float);
   BDV_REQUIRE(lds <= 60000, "bdv_lsc_fwd: D + K*P too large for LDS");
-  hipLaunchKernelGGL((head_fwd_kernel<1>), dim3(N), dim3(256), lds, HL_STREAM, x, w, (const float*)nullptr, sim, xnorm, wnorm,
+  hipLaunchKernelGGL((head_fwd_kernel<1>), dim3((N + HEAD_RB - 1) / HEAD_RB), dim3(256), lds, HL_STREAM, x, w, (const float*)nullptr, sim, xnorm, wnorm,
                      cosbuf, N, D, K, P);
   BDV_LAUNCH_CHECK("bdv_lsc_fwd");
   return BDV_OK;
@@ -458,9 +514,9 @@ extern "C" int bdv_lsc_bwd(const float* dsim, const float* x, const float* w, co
 
 extern "C" int bdv_linear_fwd(const float* x, const float* w, const float* b, float* out, int N, int D, int K, void* stream) {
   BDV_REQUIRE(x && w && out && N > 0 && D > 0 && K > 0, "bdv_linear_fwd: bad argument");
-  const size_t lds = (size_t)(D + K) * sizeof(float);
+  const size_t lds = (size_t)HEAD_RB * (D + K) * sizeof(float);
   BDV_REQUIRE(lds <= 60000, "bdv_linear_fwd: D + K too large for LDS");
-  hipLaunchKernelGGL((head_fwd_kernel<0>), dim3(N), dim3(256), lds, HL_STREAM, x, w, b, out, (float*)nullptr, (float*)nullptr,
+  hipLaunchKernelGGL((head_fwd_kernel<0>), dim3((N + HEAD_RB - 1) / HEAD_RB), dim3(256), lds, HL_STREAM, x, w, b, out, (float*)nullptr, (float*)nullptr,
                      (float*)nullptr, N, D, K, 1);
   BDV_LAUNCH_CHECK("bdv_linear_fwd");
   return BDV_OK;
@@ -469,13 +525,15 @@ extern "C" int bdv_linear_fwd(const float* x, const float* w, const float* b, fl
 extern "C" int bdv_linear_bwd(const float* dout, const float* x, const float* w, float* dx, float* dw, float* db, float beta_w,
                               int N, int D, int K, void* stream) {
   BDV_REQUIRE(dout && x && w && N > 0 && D > 0 && K > 0, "bdv_linear_bwd: bad argument");
-  BDV_REQUIRE((size_t)K * 4 <= 60000 && (size_t)N * 4 <= 60000, "bdv_linear_bwd: N or K too large for LDS");
+  BDV_REQUIRE((size_t)K * HEAD_RB * 4 <= 60000 && (size_t)N * 8 * 4 <= 60000, "bdv_linear_bwd: N or K too large for LDS");
   if (dx != nullptr) {
-    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(N), dim3(256), (size_t)K * 4, HL_STREAM, dout, w, dx, N, D, K);
+    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((N + HEAD_RB - 1) / HEAD_RB), dim3(256), (size_t)K * HEAD_RB * 4, HL_STREAM, dout, w,
+                       dx, N, D, K);
     BDV_LAUNCH_CHECK("bdv_linear_bwd(dx)");
   }
   if (dw != nullptr) {
-    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(K), dim3(256), (size_t)N * 4, HL_STREAM, dout, x, dw, db, beta_w, N, D, K);
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((K + 7) / 8, (D + 255) / 256), dim3(256), (size_t)N * 8 * 4, HL_STREAM, dout, x, dw,
+                       db, beta_w, N, D, K);
     BDV_LAUNCH_CHECK("bdv_linear_bwd(dw)");
   }
   return BDV_OK;

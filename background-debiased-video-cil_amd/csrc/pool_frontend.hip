@@ -17,76 +17,96 @@ __global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float* __rest
 }
 
 // MaxPool2d(3, 2, 1) NHWC; thread = (output pixel, 4 channels).  First maximum in (r,s) scan order wins.
+// grid.y = (frame, output row): the only division left per thread is the small 32-bit one by the channel-vector count.
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ out,
                                                            uchar4* __restrict__ idx, int N, int H, int W, int CV, int Ho, int Wo) {
-  const int64_t total = (int64_t)N * Ho * Wo * CV;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int c4 = (int)(i % CV);
-    int64_t pix = i / CV;
-    const int wo = (int)(pix % Wo);
-    pix /= Wo;
-    const int ho = (int)(pix % Ho);
-    const int n = (int)(pix / Ho);
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    uchar4 mi = make_uchar4(255, 255, 255, 255);
+  for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
+    const int n = row / Ho, ho = row - n * Ho;
+    const float4* xin = x + (int64_t)n * H * W * CV;
+    const int64_t orow = ((int64_t)n * Ho + ho) * Wo * CV;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Wo * CV; i += gridDim.x * blockDim.x) {
+      const int wo = i / CV, c4 = i - wo * CV;
+      float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      uchar4 mi = make_uchar4(255, 255, 255, 255);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int hi = 2 * ho - 1 + r;
-      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int r = 0; r < 3; ++r) {
+        const int hi = 2 * ho - 1 + r;
+        if ((unsigned)hi >= (unsigned)H) continue;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int wi = 2 * wo - 1 + s;
-        if ((unsigned)wi >= (unsigned)W) continue;
-        const float4 v = x[((int64_t)(n * H + hi) * W + wi) * CV + c4];
-        const unsigned char t = (unsigned char)(r * 3 + s);
-        if (v.x > m.x || mi.x == 255) { m.x = v.x; mi.x = t; }
-        if (v.y > m.y || mi.y == 255) { m.y = v.y; mi.y = t; }
-        if (v.z > m.z || mi.z == 255) { m.z = v.z; mi.z = t; }
-        if (v.w > m.w || mi.w == 255) { m.w = v.w; mi.w = t; }
+        for (int s = 0; s < 3; ++s) {
+          const int wi = 2 * wo - 1 + s;
+          if ((unsigned)wi >= (unsigned)W) continue;
+          const float4 v = xin[(hi * W + wi) * CV + c4];
+          const unsigned char t = (unsigned char)(r * 3 + s);
+          if (v.x > m.x || mi.x == 255) { m.x = v.x; mi.x = t; }
+          if (v.y > m.y || mi.y == 255) { m.y = v.y; mi.y = t; }
+          if (v.z > m.z || mi.z == 255) { m.z = v.z; mi.z = t; }
+          if (v.w > m.w || mi.w == 255) { m.w = v.w; mi.w = t; }
+        }
       }
+      out[orow + i] = m;
+      idx[orow + i] = mi;
     }
-    out[i] = m;
-    idx[i] = mi;
   }
 }
 
-// gather form of the backward: input pixel (h,w) collects from the <= 2x2 windows that contain it
+// Backward as a gather without divergence: a thread owns the 2x2 input block (2i..2i+1, 2j..2j+1) x 4 channels.  Those
+// four pixels are covered by exactly the windows (i,j), (i,j+1), (i+1,j), (i+1,j+1), each loaded once; a pixel takes a
+// window's gradient when the stored arg-max code equals its position (r*3+s) inside that window.  Contributions are
+// added in (r, s) scan order, i.e. the same order for every launch shape.  grid.y = (frame, block row i).
+__device__ __forceinline__ void pool_take(float4& g, const uchar4 t, const float4 d, unsigned char me) {
+  if (t.x == me) g.x += d.x;
+  if (t.y == me) g.y += d.y;
+  if (t.z == me) g.z += d.z;
+  if (t.w == me) g.w += d.w;
+}
+
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restrict__ dout, const uchar4* __restrict__ idx,
                                                            float4* __restrict__ dx, int N, int H, int W, int CV, int Ho, int Wo) {
-  const int64_t total = (int64_t)N * H * W * CV;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int c4 = (int)(i % CV);
-    int64_t pix = i / CV;
-    const int w = (int)(pix % W);
-    pix /= W;
-    const int h = (int)(pix % H);
-    const int n = (int)(pix / H);
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int hn = h + 1 - r;  // = 2*ho
-      if (hn < 0 || (hn & 1)) continue;
-      const int ho = hn >> 1;
-      if (ho >= Ho) continue;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int wn = w + 1 - s;
-        if (wn < 0 || (wn & 1)) continue;
-        const int wo = wn >> 1;
-        if (wo >= Wo) continue;
-        const int64_t o = ((int64_t)(n * Ho + ho) * Wo + wo) * CV + c4;
-        const uchar4 t = idx[o];
-        const float4 d = dout[o];
-        const unsigned char me = (unsigned char)(r * 3 + s);
-        if (t.x == me) g.x += d.x;
-        if (t.y == me) g.y += d.y;
-        if (t.z == me) g.z += d.z;
-        if (t.w == me) g.w += d.w;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const uchar4 none = make_uchar4(255, 255, 255, 255);
+  for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
+    const int n = row / Ho, i = row - n * Ho;
+    const int64_t obase = (int64_t)n * Ho * Wo * CV;
+    const int64_t ibase = (int64_t)n * H * W * CV;
+    const bool down = i + 1 < Ho, h1ok = 2 * i + 1 < H;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Wo * CV; q += gridDim.x * blockDim.x) {
+      const int j = q / CV, c4 = q - j * CV;
+      const bool right = j + 1 < Wo, w1ok = 2 * j + 1 < W;
+      const int64_t o00 = obase + (i * Wo + j) * CV + c4;
+      const uchar4 t00 = idx[o00];
+      const float4 d00 = dout[o00];
+      const uchar4 t01 = right ? idx[o00 + CV] : none;
+      const float4 d01 = right ? dout[o00 + CV] : z4;
+      const uchar4 t10 = down ? idx[o00 + Wo * CV] : none;
+      const float4 d10 = down ? dout[o00 + Wo * CV] : z4;
+      const uchar4 t11 = (down && right) ? idx[o00 + (Wo + 1) * CV] : none;
+      const float4 d11 = (down && right) ? dout[o00 + (Wo + 1) * CV] : z4;
+      const int64_t p00 = ibase + ((2 * i) * W + 2 * j) * CV + c4;
+      float4 g = z4;                      // (2i, 2j): centre of window (i,j)
+      pool_take(g, t00, d00, 4);
+      dx[p00] = g;
+      if (w1ok) {                         // (2i, 2j+1): (r=1,s=0) of (i,j+1), then (1,2) of (i,j)
+        g = z4;
+        pool_take(g, t01, d01, 3);
+        pool_take(g, t00, d00, 5);
+        dx[p00 + CV] = g;
+      }
+      if (h1ok) {                         // (2i+1, 2j): (0,1) of (i+1,j), then (2,1) of (i,j)
+        g = z4;
+        pool_take(g, t10, d10, 1);
+        pool_take(g, t00, d00, 7);
+        dx[p00 + W * CV] = g;
+        if (w1ok) {                       // (2i+1, 2j+1): (0,0) of (i+1,j+1), (0,2) of (i+1,j), (2,0) of (i,j+1), (2,2) of (i,j)
+          g = z4;
+          pool_take(g, t11, d11, 0);
+          pool_take(g, t10, d10, 2);
+          pool_take(g, t01, d01, 6);
+          pool_take(g, t00, d00, 8);
+          dx[p00 + (W + 1) * CV] = g;
+        }
       }
     }
-    dx[i] = g;
   }
 }
 
@@ -186,9 +206,10 @@ extern "C" int bdv_maxpool_fwd(const float* x, float* out, uint8_t* idx, int N, 
   BDV_REQUIRE(x && out && idx && N > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, "bdv_maxpool_fwd: bad argument");
   BDV_REQUIRE(bdv_aligned16(x) && bdv_aligned16(out) && (((uintptr_t)idx) & 3) == 0, "bdv_maxpool_fwd: alignment");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)out,
-                     (uchar4*)idx, N, H, W, C / 4, Ho, Wo);
+  BDV_REQUIRE((int64_t)H * W * (C / 4) < (1ll << 31) && (int64_t)N * Ho < (1ll << 31), "bdv_maxpool_fwd: frame or batch too large");
+  const int rowv = Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((rowv + 255) / 256, N * Ho < 65535 ? N * Ho : 65535), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                     (float4*)out, (uchar4*)idx, N, H, W, C / 4, Ho, Wo);
   BDV_LAUNCH_CHECK("bdv_maxpool_fwd");
   return BDV_OK;
 }
@@ -197,8 +218,9 @@ extern "C" int bdv_maxpool_bwd(const float* dout, const uint8_t* idx, float* dx,
   BDV_REQUIRE(dout && dx && idx && N > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, "bdv_maxpool_bwd: bad argument");
   BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(dx) && (((uintptr_t)idx) & 3) == 0, "bdv_maxpool_bwd: alignment");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const int64_t total = (int64_t)N * H * W * (C / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout,
+  BDV_REQUIRE((int64_t)Ho * Wo * (C / 4) < (1ll << 31) && (int64_t)N * H < (1ll << 31), "bdv_maxpool_bwd: frame or batch too large");
+  const int rowv = Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((rowv + 255) / 256, N * Ho < 65535 ? N * Ho : 65535), dim3(256), 0, (hipStream_t)stream, (const float4*)dout,
                      (const uchar4*)idx, (float4*)dx, N, H, W, C / 4, Ho, Wo);
   BDV_LAUNCH_CHECK("bdv_maxpool_bwd");
   return BDV_OK;

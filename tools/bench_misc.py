@@ -1,0 +1,22 @@
+"""Timing of the small kernels around the conv stack at R50 / B=32 sizes.  Dev tool, GPU only."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bdvcil_amd import kernels as K
+dev = torch.device('cuda:0')
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+a = torch.randn(256, 112, 112, 64, device=dev)
+p, idx = K.maxpool_fwd(a)
+dp = torch.randn_like(p)
+print('maxpool_fwd %.1f us' % timeit(lambda: K.maxpool_fwd(a)))
+print('maxpool_bwd %.1f us' % timeit(lambda: K.maxpool_bwd(dp, idx, tuple(a.shape))))
+x = torch.randn(256, 2048, device=dev); w = torch.randn(101, 2048, device=dev) * 0.01; b = torch.zeros(101, device=dev)
+print('linear_fwd %.1f us' % timeit(lambda: K.linear_fwd(x, w, b)))
+do = torch.randn(256, 101, device=dev)
+print('linear_bwd %.1f us' % timeit(lambda: K.linear_bwd(do, x, w)))
