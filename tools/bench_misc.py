@@ -20,3 +20,8 @@ x = torch.randn(256, 2048, device=dev); w = torch.randn(101, 2048, device=dev) *
 print('linear_fwd %.1f us' % timeit(lambda: K.linear_fwd(x, w, b)))
 do = torch.randn(256, 101, device=dev)
 print('linear_bwd %.1f us' % timeit(lambda: K.linear_bwd(do, x, w)))
+for (H, C) in [(112, 64), (56, 64), (56, 256), (28, 512), (14, 1024), (7, 2048)]:
+    M = 256 * H * H
+    part = torch.randn(2, (M + 127) // 128, C, device=dev)
+    gamma = torch.ones(C, device=dev); beta = torch.zeros(C, device=dev)
+    print('bn_train_finalize M/128=%5d C=%4d: %.1f us' % (part.shape[1], C, timeit(lambda: K.bn_train_finalize(part, M, gamma, beta, 1e-5, 0.1, None, None))))
