@@ -211,3 +211,31 @@ def test_update_fc_and_state_dict_roundtrip(dev):
     with torch.no_grad():
         a, b = mod.forward_test(imgs.to(dev)), prev.forward_test(imgs.to(dev))
     assert torch.equal(a, b) and a.shape == (1, 9)
+
+
+def test_multi_step_training_tracks_the_oracle(dev):
+    """Six SGD steps (momentum, weight decay, clip 1.0, the reference's parameter groups) on a fixed batch: the HIP path
+    and the CPU oracle start from the same weights and must follow the same loss curve, and the loss must go down
+    (end-to-end sign/scale check of forward, backward and the fused optimizer)."""
+    import bdvcil_amd as bd
+    K_ = 7
+    ref, mod, _ = _pair(18, 'LocalSimilarityClassifier', 'LSCLoss', K=K_, dev=dev, seed=3)
+    imgs, labels = _clips(4, 8, 64, K_, seed=5)
+    ref.train(); mod.train()
+    opt_ref = O.build_sgd(ref, lr=0.01)
+    opt = bd.build_optimizer(mod, dict(type='SGD', constructor='CILTSMOptimizerConstructorImprovised',
+                                       paramwise_cfg=dict(fc_lr_scale_factor=5.0), lr=0.01, momentum=0.9, weight_decay=1e-4))
+    engine = bd.TrainEngine(mod, opt, grad_clip=1.0)
+    batch = dict(imgs=imgs.to(dev), label=labels.to(dev))
+    ref_curve, hip_curve = [], []
+    for _ in range(6):
+        opt_ref.zero_grad(set_to_none=True)
+        loss = ref(imgs, labels)['loss_cls']
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        opt_ref.step()
+        ref_curve.append(loss.item())
+        hip_curve.append(engine.step(batch)['loss_cls'].item())
+    assert hip_curve[-1] < hip_curve[0]
+    for a, b in zip(hip_curve, ref_curve):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (hip_curve, ref_curve)
