@@ -390,9 +390,10 @@ extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shi
 
 extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, const float* y, const float* gamma,
                                const float* save_mean, const float* save_invstd, float* dy, float* fused_coef, float* dgamma,
-                               float* dbeta, float beta_acc, int64_t M, int C, int relu, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               float* dbeta, float beta_acc, int64_t M, int C, int relu, const float* stat_partial,
+                               int stat_rows, void* workspace, size_t workspace_bytes, void* stream) {
   BDV_REQUIRE(dout && y && gamma && save_mean && save_invstd && workspace, "bdv_bn_backward: null pointer");
+  BDV_REQUIRE(stat_partial == nullptr || (stat_rows > 0 && bdv_aligned16(stat_partial)), "bdv_bn_backward: bad stat_partial");
   BDV_REQUIRE(dy || fused_coef, "bdv_bn_backward: give dy and/or fused_coef");
   BDV_REQUIRE(!relu || (relu_mask && C % 32 == 0), "bdv_bn_backward: relu needs the forward ReLU mask (C %% 32 == 0)");
   BDV_REQUIRE(M > 0 && bn_c_ok(C), "bdv_bn_backward: unsupported M=%lld C=%d", (long long)M, C);
@@ -407,15 +408,23 @@ extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, con
   float* p2 = p1 + MAX_RB_TIMES_C;
   float* coef = p2 + MAX_RB_TIMES_C;
   hipStream_t s = (hipStream_t)stream;
-  if (relu)
-    hipLaunchKernelGGL((bn_bwd_partial_kernel<true>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean, save_invstd,
-                       p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
-  else
-    hipLaunchKernelGGL((bn_bwd_partial_kernel<false>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean, save_invstd,
-                       p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
-  BDV_LAUNCH_CHECK("bdv_bn_backward(partial)");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)p1, (const float*)p2, b.RB,
-                     M, C, gamma, save_invstd, dgamma, dbeta, beta_acc, coef, save_mean, fused_coef);
+  const float *q1 = p1, *q2 = p2;
+  int rows = b.RB;
+  if (stat_partial != nullptr) {  // the producer of dout (a dgrad epilogue) already reduced per 128-row tile
+    q1 = stat_partial;
+    q2 = stat_partial + (size_t)stat_rows * C;
+    rows = stat_rows;
+  } else {
+    if (relu)
+      hipLaunchKernelGGL((bn_bwd_partial_kernel<true>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean,
+                         save_invstd, p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
+    else
+      hipLaunchKernelGGL((bn_bwd_partial_kernel<false>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean,
+                         save_invstd, p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
+    BDV_LAUNCH_CHECK("bdv_bn_backward(partial)");
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, q1, q2, rows, M, C, gamma, save_invstd, dgamma,
+                     dbeta, beta_acc, coef, save_mean, fused_coef);
   BDV_LAUNCH_CHECK("bdv_bn_backward(finalize)");
   if (dy == nullptr) return BDV_OK;
   const int64_t n4 = M * C / 4;

@@ -200,9 +200,9 @@ __device__ __forceinline__ void fprop_store(float* __restrict__ y, const Geom& g
 
 // dgrad store of 4 consecutive input channels of pixel `row`: temporal un-shift scatter + optional masked
 // residual add (see the kernel comment).  col % 4 == 0 and fold % 4 == 0, so the 4 channels share a shift class.
-__device__ __forceinline__ void dgrad_store4(float* __restrict__ dx, const float* __restrict__ add_src,
-                                             const uint32_t* __restrict__ add_mask, const Geom& g, int HW, float rcp_HW,
-                                             int row, int col, float4 v) {
+__device__ __forceinline__ size_t dgrad_store4(float* __restrict__ dx, const float* __restrict__ add_src,
+                                               const uint32_t* __restrict__ add_mask, const Geom& g, int HW, float rcp_HW,
+                                               int row, int col, float4& v) {
   const int cls = shift_class(col, g.fold);
   int drow = row;
   if (cls != 0) {
@@ -232,6 +232,67 @@ __device__ __forceinline__ void dgrad_store4(float* __restrict__ dx, const float
     v.w += a.w;
   }
   *reinterpret_cast<float4*>(dx + o) = v;
+  return o;
+}
+
+// BatchNorm-backward statistics of the tensor a dgrad produces, taken in its epilogue (bdv_bn_stat_fuse): the dx a
+// thread stores is the gradient w.r.t. the BN(+ReLU) output of the previous conv unit, so  sum(g)  and  sum(g * xhat)
+// (g = dx * mask, xhat = (y - mean) * invstd) are accumulated per thread over its rows (a thread keeps the same 4
+// columns in every pass of the staged epilogue), reduced over the tile in fixed order and written to
+// partial[0 | 1][mt][Cin]; the separate statistics pass over dx, y and the mask disappears.
+struct BnStat {
+  const float* y;
+  const uint32_t* mask;  // may be null (no ReLU)
+  const float* mean;
+  const float* invstd;
+  float* partial;
+  int MT;
+};
+
+struct StatAcc {
+  float4 s1, s2, mu, is;
+  __device__ __forceinline__ void init(const BnStat& st, int col) {
+    s1 = s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    mu = *reinterpret_cast<const float4*>(st.mean + col);
+    is = *reinterpret_cast<const float4*>(st.invstd + col);
+  }
+  __device__ __forceinline__ void add(const BnStat& st, size_t o, float4 v) {
+    const float4 yv = *reinterpret_cast<const float4*>(st.y + o);
+    if (st.mask != nullptr) {
+      const unsigned nib = (st.mask[o >> 5] >> (o & 31)) & 0xFu;
+      v.x = (nib & 1u) ? v.x : 0.f;
+      v.y = (nib & 2u) ? v.y : 0.f;
+      v.z = (nib & 4u) ? v.z : 0.f;
+      v.w = (nib & 8u) ? v.w : 0.f;
+    }
+    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+    s2.x += v.x * ((yv.x - mu.x) * is.x);
+    s2.y += v.y * ((yv.y - mu.y) * is.y);
+    s2.z += v.z * ((yv.z - mu.z) * is.z);
+    s2.w += v.w * ((yv.w - mu.w) * is.w);
+  }
+};
+
+// tile reduction of the per-thread sums: thread = (row group tid / V, column vector tid % V), V = BN / 4
+template <int BN>
+__device__ __forceinline__ void stat_flush(const StatAcc& a, const BnStat& st, float* __restrict__ smem, int Cin, int mt, int nt,
+                                           int tid) {
+  constexpr int V = BN / 4, G = 256 / V;
+  __syncthreads();  // every thread is done reading the staged tile
+  const int grp = tid / V, c4 = tid - grp * V;
+  *reinterpret_cast<float4*>(smem + grp * BN + 4 * c4) = a.s1;
+  *reinterpret_cast<float4*>(smem + (G + grp) * BN + 4 * c4) = a.s2;
+  __syncthreads();
+  if (tid < BN) {
+    float x = 0.f, y = 0.f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      x += smem[k * BN + tid];
+      y += smem[(G + k) * BN + tid];
+    }
+    st.partial[(size_t)mt * Cin + nt * BN + tid] = x;
+    st.partial[((size_t)st.MT + mt) * Cin + nt * BN + tid] = y;
+  }
 }
 
 // Epilogue staging: the accumulator layout (one column per lane, 16 rows in registers) would store 4 bytes per
@@ -532,7 +593,7 @@ template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                           float* __restrict__ dx, const float* __restrict__ add_src,
                                                           const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk,
-                                                          float* __restrict__ slab) {
+                                                          float* __restrict__ slab, BnStat stat) {
   constexpr int LDA = BM, LDB = BN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
@@ -659,6 +720,9 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
   // ("orphans") instead write the zero that the unreachable frame at the other clip end needs,
   // which makes the scatter a bijection over dx.
   const float rcp_HW = 1.0f / (float)HW;
+  const bool do_stat = stat.y != nullptr;  // host: only with stride 1 and no temporal shift (rows map one to one)
+  StatAcc sa;
+  if (do_stat) sa.init(stat, nt * BN + 4 * (tid % (BN / 4)));
   staged_epilogue<BM, BN, WM, WN>(acc, smem, tid, [&](int tr, int tc, float4 v) {
     const int mrow = mt * BM + tr;
     if (mrow >= Mc) return;
@@ -669,14 +733,17 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
       const int hc = rem / Wc;
       row = (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
     }
-    dgrad_store4(dx, add_src, add_mask, g, HW, rcp_HW, row, nt * BN + tc, v);
+    const size_t o = dgrad_store4(dx, add_src, add_mask, g, HW, rcp_HW, row, nt * BN + tc, v);
+    if (do_stat) sa.add(stat, o, v);
   });
+  if (do_stat) stat_flush<BN>(sa, stat, smem, g.Cin, mt, nt, tid);
 }
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_dgrad_fixup_kernel(const float* __restrict__ slab, float* __restrict__ dx,
                                                                 const float* __restrict__ add_src,
-                                                                const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk) {
+                                                                const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk,
+                                                                BnStat stat) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NACC = TM * TN * 16;
   __shared__ __attribute__((aligned(16))) float smem[WM * 32 * BN];
@@ -696,10 +763,16 @@ __global__ __launch_bounds__(256) void conv_dgrad_fixup_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] += src[(size_t)((i * TN + j) * 16 + e) * 256];
   }
+  const bool do_stat = stat.y != nullptr;
+  StatAcc sa;
+  if (do_stat) sa.init(stat, nt * BN + 4 * (tid % (BN / 4)));
   staged_epilogue<BM, BN, WM, WN>(acc, smem, tid, [&](int tr, int tc, float4 v) {
     const int row = mt * BM + tr;
-    if (row < g.M) dgrad_store4(dx, add_src, add_mask, g, HW, rcp_HW, row, nt * BN + tc, v);
+    if (row >= g.M) return;
+    const size_t o = dgrad_store4(dx, add_src, add_mask, g, HW, rcp_HW, row, nt * BN + tc, v);
+    if (do_stat) sa.add(stat, o, v);
   });
+  if (do_stat) stat_flush<BN>(sa, stat, smem, g.Cin, mt, nt, tid);
 }
 
 // =========================================================================================
@@ -1221,10 +1294,31 @@ extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bd
   return BDV_OK;
 }
 
+extern "C" int bdv_conv_dgrad_stat_rows(const bdv_conv_geom* gg) {
+  if (check_geom(gg, "bdv_conv_dgrad_stat_rows")) return 0;
+  const int64_t M = (int64_t)gg->N * gg->H * gg->W;
+  return (int)((M + 127) / 128);
+}
+
 extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const float* add_src,
-                              const uint32_t* add_mask_src, const bdv_conv_geom* gg, void* workspace, size_t workspace_bytes,
-                              void* stream) {
+                              const uint32_t* add_mask_src, const bdv_conv_geom* gg, const bdv_bn_stat_fuse* bn_stat,
+                              void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_dgrad")) return e;
+  BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  if (bn_stat != nullptr) {
+    BDV_REQUIRE(gg->stride == 1 && gg->fold == 0,
+                "bdv_conv_dgrad: fused BatchNorm statistics need stride 1 and no temporal shift (dx rows map one to one)");
+    BDV_REQUIRE(bn_stat->y && bn_stat->mean && bn_stat->invstd && bn_stat->partial, "bdv_conv_dgrad: null pointer in bdv_bn_stat_fuse");
+    BDV_REQUIRE(bdv_aligned16(bn_stat->y) && bdv_aligned16(bn_stat->mean) && bdv_aligned16(bn_stat->invstd) &&
+                    bdv_aligned16(bn_stat->partial), "bdv_conv_dgrad: bdv_bn_stat_fuse pointers must be 16-byte aligned");
+    BDV_REQUIRE(bn_stat->relu_mask == nullptr || gg->Cin % 32 == 0, "bdv_conv_dgrad: a ReLU mask needs Cin %% 32 == 0");
+    stat.y = bn_stat->y;
+    stat.mask = bn_stat->relu_mask;
+    stat.mean = bn_stat->mean;
+    stat.invstd = bn_stat->invstd;
+    stat.partial = bn_stat->partial;
+    stat.MT = bdv_conv_dgrad_stat_rows(gg);
+  }
   BDV_REQUIRE(dy && w && dx, "bdv_conv_dgrad: null pointer");
   BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(w) && bdv_aligned16(dx) && bdv_aligned16(workspace),
               "bdv_conv_dgrad: pointers must be 16-byte aligned");
@@ -1242,16 +1336,16 @@ extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const 
     fprintf(stderr, "[bdv plan] dgrad %dx%d Cin %d Cout %d k%d s%d: tiles %d nk %d -> dp %d rem %d split %d\n", g.H, g.W,
             g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
   if (p.wide)
-    hipLaunchKernelGGL((conv_dgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, p.NT, p.wk, slab);
+    hipLaunchKernelGGL((conv_dgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, p.NT, p.wk, slab, stat);
   else
-    hipLaunchKernelGGL((conv_dgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, p.NT, p.wk, slab);
+    hipLaunchKernelGGL((conv_dgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, p.NT, p.wk, slab, stat);
   BDV_LAUNCH_CHECK("bdv_conv_dgrad");
   if (p.wk.split > 1) {
     const dim3 fg(p.wk.rem_tiles);
     if (p.wide)
-      hipLaunchKernelGGL((conv_dgrad_fixup_kernel<128, 128, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, dx, add_src, add_mask_src, g, p.NT, p.wk);
+      hipLaunchKernelGGL((conv_dgrad_fixup_kernel<128, 128, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, dx, add_src, add_mask_src, g, p.NT, p.wk, stat);
     else
-      hipLaunchKernelGGL((conv_dgrad_fixup_kernel<128, 64, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, dx, add_src, add_mask_src, g, p.NT, p.wk);
+      hipLaunchKernelGGL((conv_dgrad_fixup_kernel<128, 64, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, dx, add_src, add_mask_src, g, p.NT, p.wk, stat);
     BDV_LAUNCH_CHECK("bdv_conv_dgrad(fixup)");
   }
   return BDV_OK;

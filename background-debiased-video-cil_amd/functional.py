@@ -40,6 +40,9 @@ _SIDE = {'enabled': _os.environ.get('BDVCIL_WGRAD_SIDE_STREAM', '0') != '0', 'st
 # dy, i.e. it only saves one pass in four, and the heavier loader costs the wgrad kernels more than that on MI355X
 # (measured on TSM-R50 bs32: 395 clips/s fused vs 400 unfused).  Off by default; BDVCIL_FUSE_BN_BWD=1 enables it.
 FUSE_BN_BWD = _os.environ.get('BDVCIL_FUSE_BN_BWD', '0') != '0'
+# BatchNorm-backward statistics of a unit taken in the epilogue of the dgrad that produces its output gradient
+# (bdv_conv_dgrad with a bdv_bn_stat_fuse): removes the separate pass over dout, y and the mask for the inner units.
+FUSE_BN_STATS = _os.environ.get('BDVCIL_FUSE_BN_STATS', '1') != '0'
 
 
 def set_side_stream_enabled(flag: bool):
@@ -127,16 +130,16 @@ def _conv_bn_forward(x, w_krsc, g, bn, gamma, beta, training):
     return y, None, None, scale, shift
 
 
-def _bn_wgrad_backward(dout, mask, y, gamma, mean, invstd, inp, geom, need_dw):
+def _bn_wgrad_backward(dout, mask, y, gamma, mean, invstd, inp, geom, need_dw, stat_partial=None):
     """BatchNorm(+ReLU) backward of one conv+BN unit followed by the conv's wgrad -> (dy, dgamma, dbeta, dw | None).
     With a weight gradient wanted (and no side stream) only the BN reductions run as their own kernels; the
     elementwise apply step happens inside the wgrad kernel, which also writes dy for the dgrad."""
     if need_dw and not _SIDE['enabled'] and FUSE_BN_BWD:
-        coef, dg, db = K.bn_backward(dout, mask, y, gamma, mean, invstd, True, reduce_only=True)
+        coef, dg, db = K.bn_backward(dout, mask, y, gamma, mean, invstd, True, reduce_only=True, stat_partial=stat_partial)
         dy = torch.empty_like(y)
         dw = K.conv_wgrad(None, inp, geom, bn_fuse=(dout, mask, y, coef, dy))
         return dy, dg, db, dw
-    dy, dg, db = K.bn_backward(dout, mask, y, gamma, mean, invstd, True)
+    dy, dg, db = K.bn_backward(dout, mask, y, gamma, mean, invstd, True, stat_partial=stat_partial)
     dw = wgrad_overlapped(dy, inp, geom) if need_dw else None
     return dy, dg, db, dw
 
@@ -250,17 +253,23 @@ class ResBlockFn(torch.autograd.Function):
         need_dx = need[0]
 
         # main branch, last unit first.  ``d`` is the gradient w.r.t. the unit's (post-ReLU) output.
-        d = dout
+        d, part = dout, None
         for i in range(n_main - 1, -1, -1):
             wt, gm = params[3 * i], params[3 * i + 1]
             inp = acts[i - 1] if i > 0 else x
             dy, dg, db, dw = _bn_wgrad_backward(d, masks[i], ys[i], gm, means[i], invstds[i], inp, ctx.geoms[i],
-                                                need[3 + 3 * i])
+                                                need[3 + 3 * i], stat_partial=part)
             grads[3 * i + 1], grads[3 * i + 2] = dg, db
             if dw is not None:
                 grads[3 * i] = dw.permute(0, 3, 1, 2)
+            part = None
             if i > 0:
-                d = K.conv_dgrad(dy, weight_krsc(wt), ctx.geoms[i])
+                gi = ctx.geoms[i]
+                if FUSE_BN_STATS and gi.stride == 1 and gi.fold == 0:
+                    # this dgrad produces the gradient entering unit i-1's BN+ReLU: take its statistics in the epilogue
+                    d, part = K.conv_dgrad(dy, weight_krsc(wt), gi, bn_stats=(ys[i - 1], masks[i - 1], means[i - 1], invstds[i - 1]))
+                else:
+                    d = K.conv_dgrad(dy, weight_krsc(wt), gi)
             else:
                 dy_first = dy
 

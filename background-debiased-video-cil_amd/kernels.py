@@ -11,7 +11,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from ._lib import BnBwdFuse, ConvGeom, check, lib
+from ._lib import BnBwdFuse, BnStatFuse, ConvGeom, check, lib
 
 _WS = {}  # (device index, tag) -> workspace tensor (grown on demand, never shrunk)
 
@@ -86,7 +86,10 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional[torch.Tensor] = None,
                add_mask_src: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-               ws_tag: str = 'conv') -> torch.Tensor:
+               ws_tag: str = 'conv', bn_stats=None):
+    """``bn_stats = (y, relu_mask | None, mean, invstd)`` of the conv unit whose output gradient this dgrad produces:
+    the BatchNorm-backward statistics are then taken in the epilogue and ``(dx, partial)`` is returned; pass ``partial``
+    to ``bn_backward(stat_partial=...)``.  Needs stride 1 and no temporal shift."""
     _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
     _chk(w, (g.Cout, g.R, g.S, g.Cin), name='w')
     dx = out if out is not None else torch.empty((g.N, g.H, g.W, g.Cin), dtype=torch.float32, device=dy.device)
@@ -97,10 +100,22 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
             raise ValueError('conv_dgrad: in-place add_src is not allowed with a temporal shift (scatter epilogue)')
     if add_mask_src is not None:
         _chk(add_mask_src, (g.N * g.H * g.W * g.Cin // 32,), dtype=torch.int32, name='add_mask_src')
+    fuse = partial = None
+    if bn_stats is not None:
+        y, mask, mean, invstd = bn_stats
+        _chk(y, (g.N, g.H, g.W, g.Cin), name='y')
+        _chk(mean, (g.Cin,), name='mean')
+        _chk(invstd, (g.Cin,), name='invstd')
+        if mask is not None:
+            _chk(mask, (y.numel() // 32,), dtype=torch.int32, name='relu_mask')
+        rows = lib().bdv_conv_dgrad_stat_rows(ctypes.byref(g))
+        partial = torch.empty((2, rows, g.Cin), dtype=torch.float32, device=dy.device)
+        fuse = BnStatFuse(y.data_ptr(), mask.data_ptr() if mask is not None else None, mean.data_ptr(), invstd.data_ptr(),
+                          partial.data_ptr())
     ws = _conv_ws(g, 1, dy.device, ws_tag)
-    check(lib().bdv_conv_dgrad(_p(dy), _p(w), _p(dx), _p(add_src), _p(add_mask_src), ctypes.byref(g), _p(ws), ws.numel(),
-                               _stream()), 'bdv_conv_dgrad')
-    return dx
+    check(lib().bdv_conv_dgrad(_p(dy), _p(w), _p(dx), _p(add_src), _p(add_mask_src), ctypes.byref(g),
+                               ctypes.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), _stream()), 'bdv_conv_dgrad')
+    return dx if bn_stats is None else (dx, partial)
 
 
 def conv_wgrad(dy: Optional[torch.Tensor], x: torch.Tensor, g: ConvGeom, dw: Optional[torch.Tensor] = None,
@@ -209,10 +224,11 @@ def bn_apply(y, scale, shift, res=None, relu=True, out=None, want_mask=False):
 
 
 def bn_backward(dout, relu_mask, y, gamma, save_mean, save_invstd, relu, dgamma=None, dbeta=None, beta_acc=0.0, dy=None,
-                reduce_only=False):
+                reduce_only=False, stat_partial=None):
     """Returns (dy, dgamma, dbeta).  ``relu_mask`` is the bit mask from ``bn_apply(want_mask=True)`` (needed when relu).
     ``reduce_only``: only the reductions run and the first return value is the ``(4, C)`` coefficient table that
-    ``conv_wgrad(bn_fuse=...)`` consumes (dy is then formed inside the wgrad kernel)."""
+    ``conv_wgrad(bn_fuse=...)`` consumes (dy is then formed inside the wgrad kernel).
+    ``stat_partial``: the ``(2, rows, C)`` tile sums from ``conv_dgrad(bn_stats=...)``; the statistics pass is skipped."""
     C = y.shape[-1]
     M = y.numel() // C
     _chk(dout, tuple(y.shape), name='dout')
@@ -233,9 +249,15 @@ def bn_backward(dout, relu_mask, y, gamma, save_mean, save_invstd, relu, dgamma=
         d, coef = (dy if dy is not None else torch.empty_like(y)), None
         _chk(d, tuple(y.shape), name='dy')
     ws = _bn_ws(M, C, y.device)
+    srows = 0
+    if stat_partial is not None:
+        _chk(stat_partial, name='stat_partial')
+        if stat_partial.dim() != 3 or stat_partial.shape[0] != 2 or stat_partial.shape[2] != C:
+            raise ValueError(f'bn_backward: stat_partial {tuple(stat_partial.shape)} is not (2, rows, {C})')
+        srows = stat_partial.shape[1]
     check(lib().bdv_bn_backward(_p(dout), _p(relu_mask if relu else None), _p(y), _p(gamma), _p(save_mean), _p(save_invstd),
-                                _p(d), _p(coef), _p(dgamma), _p(dbeta), float(beta_acc), M, C, int(bool(relu)), _p(ws),
-                                ws.numel(), _stream()), 'bdv_bn_backward')
+                                _p(d), _p(coef), _p(dgamma), _p(dbeta), float(beta_acc), M, C, int(bool(relu)),
+                                _p(stat_partial), srows, _p(ws), ws.numel(), _stream()), 'bdv_bn_backward')
     return (coef if reduce_only else d), dgamma, dbeta
 
 

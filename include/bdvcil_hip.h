@@ -76,13 +76,26 @@ typedef struct bdv_bn_bwd_fuse {
   float* dy_out;             /* [N,Ho,Wo,Cout] */
 } bdv_bn_bwd_fuse;
 
+/* BatchNorm-backward statistics fused into dgrad: dx (the gradient w.r.t. the BN(+ReLU) output of the PREVIOUS conv unit,
+ * whose saved conv output is y) is reduced in the dgrad epilogue to partial[0][r][c] = sum(g), partial[1][r][c] =
+ * sum(g * xhat) per 128-row tile r (g = dx * mask, xhat = (y - mean) * invstd; rows = bdv_conv_dgrad_stat_rows(g));
+ * bdv_bn_backward(stat_partial = ...) then skips its own statistics pass.  Needs stride 1 and fold 0. */
+typedef struct bdv_bn_stat_fuse {
+  const float* y;            /* [N,H,W,Cin] conv output of the previous unit */
+  const uint32_t* relu_mask; /* 1 bit per element of dx, or NULL (no ReLU) */
+  const float* mean;         /* [Cin] saved batch mean */
+  const float* invstd;       /* [Cin] */
+  float* partial;            /* float[2][rows][Cin] */
+} bdv_bn_stat_fuse;
+int bdv_conv_dgrad_stat_rows(const bdv_conv_geom* g);
+
 /* dgrad: dx[N,H,W,Cin] = unshift(conv_transpose(dy, w)) + (add_src ? add_src * mask : 0),
  * mask = bit e of add_mask_src (the ReLU sign mask written by bdv_bn_apply) when add_mask_src != NULL
  * (fused ReLU-backward of the identity path).
  * Replaces autograd of F.conv2d w.r.t. its input and of TemporalShift.shift. */
 int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const float* add_src,
-                   const uint32_t* add_mask_src, const bdv_conv_geom* g, void* workspace, size_t workspace_bytes,
-                   void* stream);
+                   const uint32_t* add_mask_src, const bdv_conv_geom* g, const bdv_bn_stat_fuse* bn_stat, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* wgrad: dw[Cout,R,S,Cin] = beta * dw + sum_pixels dy (x) shift(x).  Deterministic split-K:
  * partial slabs go to `workspace`, a second kernel reduces them in fixed order. */
@@ -118,10 +131,11 @@ int bdv_bn_apply(const float* y, const float* scale, const float* shift, const f
  * (dout, relu_mask) -- see bdv_conv_dgrad(add_src, add_mask_src) and bdv_relu_bwd. */
 /* dy may be NULL when fused_coef (float[4][C]) is given: then only the reductions run and the conv backward kernels
  * apply  dy = A*g - Bc*(y - mean) - Cc  inside their operand loaders (bdv_bn_bwd_fuse), so dy never touches HBM. */
+/* stat_partial (optional): float[2][stat_rows][C] written by bdv_conv_dgrad(bn_stat); the statistics pass is skipped. */
 int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, const float* y, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dy, float* fused_coef, float* dgamma,
-                    float* dbeta, float beta_acc, int64_t M, int C, int relu, void* workspace,
-                    size_t workspace_bytes, void* stream);
+                    float* dbeta, float beta_acc, int64_t M, int C, int relu, const float* stat_partial, int stat_rows,
+                    void* workspace, size_t workspace_bytes, void* stream);
 /* g = dout * relu_mask (+ add) : masked gradient for an identity path that has no conv behind it */
 int bdv_relu_bwd(const float* dout, const uint32_t* relu_mask, const float* add, float* g, int64_t numel, void* stream);
 /* out = a + b (gradient junctions) */

@@ -1,6 +1,7 @@
 """Parity of the implicit-GEMM conv kernels (fprop / dgrad / wgrad, with the fused temporal shift)
 against the CPU oracle: torch fp32 conv2d + oracle.temporal_shift + autograd, same seeded inputs.
 Tolerance: fp32 arithmetic on both sides, only the summation order differs -> 2e-5 of the output scale."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -228,3 +229,54 @@ def test_wgrad_fused_bn_backward(case, relu, dev):
     _close(dy, dy2, tol=1e-5)
     with pytest.raises(ValueError):
         K.conv_wgrad(dy2, xd, g, bn_fuse=(doutd, mask, yd, coef, dy))
+
+
+# BatchNorm-backward statistics taken in the dgrad epilogue: dx of this conv is the gradient entering the previous
+# unit's BN(+ReLU); partial[0] / partial[1] summed over the row tiles must equal sum(g) and sum(g * xhat), and
+# bn_backward fed with them must give what the separate statistics pass gives.
+STAT_CASES = [
+    (8, 14, 14, 64, 128, 1, 1, 0, 1, 0),      # Cin = 64: 128x64 tiles
+    (16, 6, 6, 256, 128, 1, 1, 0, 1, 0),      # ragged M (576 rows), 128x128 tiles
+    (2, 9, 9, 128, 128, 3, 1, 1, 1, 0),       # 3x3
+    (64, 14, 14, 256, 256, 3, 1, 1, 1, 0),    # 98 x 2 = 196 tiles: one partial round, K-split fix-up path
+    (8, 7, 7, 256, 512, 3, 1, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize('case', STAT_CASES)
+@pytest.mark.parametrize('relu', [True, False])
+def test_dgrad_fused_bn_backward_statistics(case, relu, dev):
+    from bdvcil_amd import kernels as K
+    N, H, W, Cin, Cout, R, st, pad, T, fold = case
+    gen = torch.Generator().manual_seed(31)
+    _, w = _mk(case, 6)
+    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
+    dy = torch.randn(N, g.Ho, g.Wo, Cout, generator=gen).to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    yprev = torch.randn(N, H, W, Cin, generator=gen).to(dev)            # conv output of the previous unit
+    gamma = (torch.rand(Cin, generator=gen) + 0.5).to(dev)
+    beta = torch.zeros(Cin, device=dev)
+    mean, invstd, scale, shift = K.bn_train_stats(yprev, gamma, beta, 1e-5, 0.1, None, None)
+    mask = None
+    if relu:
+        _, mask = K.bn_apply(yprev, scale, shift, None, True, want_mask=True)
+    dx_ref = K.conv_dgrad(dy, wd, g)
+    dx, part = K.conv_dgrad(dy, wd, g, bn_stats=(yprev, mask, mean, invstd))
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    assert part.shape == (2, (N * H * W + 127) // 128, Cin)
+    gm = dx_ref.double().cpu()
+    if relu:
+        bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder='little').astype(bool).reshape(N, H, W, Cin)
+        gm = gm * torch.from_numpy(bits)
+    xhat = (yprev.double().cpu() - mean.double().cpu()) * invstd.double().cpu()
+    s1 = gm.sum(dim=(0, 1, 2))
+    s2 = (gm * xhat).sum(dim=(0, 1, 2))
+    _close(part[0].double().sum(0).cpu(), s1, tol=1e-5)
+    _close(part[1].double().sum(0).cpu(), s2, tol=1e-5)
+    a = K.bn_backward(dx_ref, mask, yprev, gamma, mean, invstd, relu)
+    b = K.bn_backward(dx_ref, mask, yprev, gamma, mean, invstd, relu, stat_partial=part)
+    for u, v in zip(a, b):
+        _close(u, v, tol=2e-5)
+    with pytest.raises(Exception):
+        K.conv_dgrad(dy, wd, K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, 8, 8), bn_stats=(yprev, mask, mean, invstd))
