@@ -1220,11 +1220,6 @@ WgradPlan plan_wgrad(const bdv_conv_geom* g) {
 
 }  // namespace
 
-extern "C" void bdv_debug_set(int knob, int value) {
-  (void)knob;
-  (void)value;
-}
-
 extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
   if (check_geom(gg, "bdv_conv_workspace_bytes")) return 0;
   if (kind == 2) {
