@@ -198,43 +198,6 @@ __device__ __forceinline__ void fprop_store(float* __restrict__ y, const Geom& g
   if (row < g.M) y[(size_t)row * g.Cout + col] = v;
 }
 
-// dgrad store of 4 consecutive input channels of pixel `row`: temporal un-shift scatter + optional masked
-// residual add (see the kernel comment).  col % 4 == 0 and fold % 4 == 0, so the 4 channels share a shift class.
-__device__ __forceinline__ size_t dgrad_store4(float* __restrict__ dx, const float* __restrict__ add_src,
-                                               const uint32_t* __restrict__ add_mask, const Geom& g, int HW, float rcp_HW,
-                                               int row, int col, float4& v) {
-  const int cls = shift_class(col, g.fold);
-  int drow = row;
-  if (cls != 0) {
-    int n, rem;
-    fast_divmod(row, HW, rcp_HW, n, rem);
-    const int t = n % g.T;
-    if ((unsigned)(t + cls) < (unsigned)g.T) {
-      drow = row + cls * HW;
-    } else {
-      drow = row - cls * (g.T - 1) * HW;
-      v = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  const size_t o = (size_t)drow * g.Cin + col;
-  if (add_src != nullptr) {
-    float4 a = *reinterpret_cast<const float4*>(add_src + o);
-    if (add_mask != nullptr) {
-      const unsigned nib = (add_mask[o >> 5] >> (o & 31)) & 0xFu;
-      a.x = (nib & 1u) ? a.x : 0.f;
-      a.y = (nib & 2u) ? a.y : 0.f;
-      a.z = (nib & 4u) ? a.z : 0.f;
-      a.w = (nib & 8u) ? a.w : 0.f;
-    }
-    v.x += a.x;
-    v.y += a.y;
-    v.z += a.z;
-    v.w += a.w;
-  }
-  *reinterpret_cast<float4*>(dx + o) = v;
-  return o;
-}
-
 // BatchNorm-backward statistics of the tensor a dgrad produces, taken in its epilogue (bdv_bn_stat_fuse): the dx a
 // thread stores is the gradient w.r.t. the BN(+ReLU) output of the previous conv unit, so  sum(g)  and  sum(g * xhat)
 // (g = dx * mask, xhat = (y - mean) * invstd) are accumulated per thread over its rows (a thread keeps the same 4
@@ -256,15 +219,7 @@ struct StatAcc {
     mu = *reinterpret_cast<const float4*>(st.mean + col);
     is = *reinterpret_cast<const float4*>(st.invstd + col);
   }
-  __device__ __forceinline__ void add(const BnStat& st, size_t o, float4 v) {
-    const float4 yv = *reinterpret_cast<const float4*>(st.y + o);
-    if (st.mask != nullptr) {
-      const unsigned nib = (st.mask[o >> 5] >> (o & 31)) & 0xFu;
-      v.x = (nib & 1u) ? v.x : 0.f;
-      v.y = (nib & 2u) ? v.y : 0.f;
-      v.z = (nib & 4u) ? v.z : 0.f;
-      v.w = (nib & 8u) ? v.w : 0.f;
-    }
+  __device__ __forceinline__ void accumulate(const float4 v, const float4 yv) {  // v: masked gradient, yv: conv output
     s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
     s2.x += v.x * ((yv.x - mu.x) * is.x);
     s2.y += v.y * ((yv.y - mu.y) * is.y);
@@ -323,6 +278,116 @@ __device__ __forceinline__ void staged_epilogue(const f32x16 (&acc)[BM / WM / 32
       emit(32 * WM * i + lr, 4 * c4, v);  // staged row lr = 32 * wave_m + r  ->  tile row 32*WM*i + lr
     }
   }
+}
+
+// dgrad epilogue: like staged_epilogue, but the per-piece work (residual / mask loads, statistics loads) is batched and
+// branch-free.  Each thread first computes the destination offsets of its PER pieces of a pass and issues all their
+// loads as buffer loads (pieces past the last row get an out-of-range offset: loads return zeros, stores are dropped),
+// then combines and stores.  With one `if (row < M)` branch per piece the compiler had serialised the pieces, i.e.
+// 16 dependent global-load latencies per tile: the conv1 sites (K loop of 2-16 steps, residual add) ran at half their
+// HBM roofline.
+// rowmap(mrow) -> dx pixel index of tile row mrow (identity for stride 1; parity-class map for stride 2).
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t rsrc, int voff, float4 v) {
+  u32x4 d;
+  d.x = __float_as_uint(v.x);
+  d.y = __float_as_uint(v.y);
+  d.z = __float_as_uint(v.z);
+  d.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, voff, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, class RowMap>
+__device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ smem, int tid,
+                                               float* __restrict__ dx, const float* __restrict__ add_src,
+                                               const uint32_t* __restrict__ add_mask, const Geom& g, int mt, int nt, int Mrows,
+                                               const BnStat& stat, RowMap&& rowmap) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int V = BN / 4;
+  constexpr int PER = WM * 32 * V / 256;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn0 = (wave % WN) * 32;
+  const int HW = g.H * g.W;
+  const float rcp_HW = 1.0f / (float)HW;
+  const int total_bytes = g.N * HW * g.Cin * 4;
+  const __amdgpu_buffer_rsrc_t dxr = __builtin_amdgcn_make_buffer_rsrc((void*)dx, 0, total_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t adr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(add_src ? add_src : dx), 0, add_src ? total_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t amr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(add_mask ? (const void*)add_mask : (const void*)dx), 0, add_mask ? total_bytes / 32 : 0, 0x00020000);
+  const bool do_stat = stat.y != nullptr;
+  const __amdgpu_buffer_rsrc_t syr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(do_stat ? stat.y : dx), 0, do_stat ? total_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t smr = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(do_stat && stat.mask ? (const void*)stat.mask : (const void*)dx), 0, do_stat && stat.mask ? total_bytes / 32 : 0, 0x00020000);
+  // the thread's 4 columns are the same for every piece (256 % V == 0)
+  const int col = nt * BN + 4 * (tid % V);
+  const int cls = shift_class(col, g.fold);
+  StatAcc sa;
+  if (do_stat) sa.init(stat, col);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    __syncthreads();  // LDS is free: K loop / previous pass finished
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) smem[(wm * 32 + acc_row(e, lane)) * BN + wn0 + 32 * WN * j + (lane & 31)] = acc[i][j][e];
+    __syncthreads();
+    constexpr int HB = PER < 4 ? PER : 4;  // pieces in flight per thread (register budget: 3 float4 + 3 words each)
+#pragma unroll
+    for (int q0 = 0; q0 < PER; q0 += HB) {
+      float4 v[HB], a[HB], yv[HB];
+      uint32_t am[HB], sm[HB];
+      int off[HB];
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+        const int lr = (tid + 256 * (q0 + u)) / V;
+        const int mrow = mt * BM + 32 * WM * i + lr;
+        const bool ok = mrow < Mrows;
+        const int row = rowmap(ok ? mrow : 0);
+        int drow = row;
+        bool zero = false;
+        if (cls != 0) {  // temporal un-shift: frame n -> n + cls inside the clip, else the zero the far clip end needs
+          int n, rem;
+          fast_divmod(row, HW, rcp_HW, n, rem);
+          const int t = n % g.T;
+          const bool inside = (unsigned)(t + cls) < (unsigned)g.T;
+          drow = inside ? row + cls * HW : row - cls * (g.T - 1) * HW;
+          zero = !inside;
+        }
+        const int o = drow * g.Cin + col;
+        off[u] = ok ? o * 4 : kOOB;
+        const float4 t4 = *reinterpret_cast<const float4*>(smem + lr * BN + 4 * (tid % V));
+        v[u] = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : t4;
+        a[u] = buf_load16(adr, off[u], 0);  // zeros when there is no add_src
+        am[u] = add_mask ? __builtin_amdgcn_raw_buffer_load_b32(amr, ok ? (o >> 5) << 2 : kOOB, 0, 0) : 0xffffffffu;
+        if (do_stat) {
+          yv[u] = buf_load16(syr, off[u], 0);
+          sm[u] = stat.mask ? __builtin_amdgcn_raw_buffer_load_b32(smr, ok ? (o >> 5) << 2 : kOOB, 0, 0) : 0xffffffffu;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+        const int sh = (off[u] >> 2) & 31;  // bit position of the piece's first channel in its mask word
+        const unsigned nib = (am[u] >> sh) & 0xFu;
+        float4 r = v[u];
+        r.x += (nib & 1u) ? a[u].x : 0.f;
+        r.y += (nib & 2u) ? a[u].y : 0.f;
+        r.z += (nib & 4u) ? a[u].z : 0.f;
+        r.w += (nib & 8u) ? a[u].w : 0.f;
+        buf_store16(dxr, off[u], r);
+        if (do_stat && off[u] != kOOB) {
+          const unsigned sn = (sm[u] >> sh) & 0xFu;
+          float4 gq;
+          gq.x = (sn & 1u) ? r.x : 0.f;
+          gq.y = (sn & 2u) ? r.y : 0.f;
+          gq.z = (sn & 4u) ? r.z : 0.f;
+          gq.w = (sn & 8u) ? r.w : 0.f;
+          sa.accumulate(gq, yv[u]);
+        }
+      }
+    }
+  }
+  if (do_stat) stat_flush<BN>(sa, stat, smem, g.Cin, mt, nt, tid);
 }
 
 // BatchNorm batch statistics fused into the fprop epilogue: per tile, the column sums of y and y^2 over the
@@ -640,7 +705,6 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
   const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;  // tile i / j of the wave: + 32*WM*i / + 32*WN*j
   const int arow = tid >> 3, kg = tid & 7;
   const int HcWc = Hc * Wc;
-  const int HW = g.H * g.W;
   const int RS = g.R * g.S;
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.N * g.Ho * g.Wo * g.Cout * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, g.Cout * RS * g.Cin * 4, 0x00020000);
@@ -719,24 +783,13 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
   // frame n + cls when that frame is inside the clip.  Rows whose target falls outside the clip
   // ("orphans") instead write the zero that the unreachable frame at the other clip end needs,
   // which makes the scatter a bijection over dx.
-  const float rcp_HW = 1.0f / (float)HW;
-  const bool do_stat = stat.y != nullptr;  // host: only with stride 1 and no temporal shift (rows map one to one)
-  StatAcc sa;
-  if (do_stat) sa.init(stat, nt * BN + 4 * (tid % (BN / 4)));
-  staged_epilogue<BM, BN, WM, WN>(acc, smem, tid, [&](int tr, int tc, float4 v) {
-    const int mrow = mt * BM + tr;
-    if (mrow >= Mc) return;
-    int row = mrow;
-    if (st != 1) {
-      const int n = mrow / HcWc;
-      const int rem = mrow - n * HcWc;
-      const int hc = rem / Wc;
-      row = (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
-    }
-    const size_t o = dgrad_store4(dx, add_src, add_mask, g, HW, rcp_HW, row, nt * BN + tc, v);
-    if (do_stat) sa.add(stat, o, v);
+  dgrad_epilogue<BM, BN, WM, WN>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
+    if (st == 1) return mrow;
+    const int n = mrow / HcWc;
+    const int rem = mrow - n * HcWc;
+    const int hc = rem / Wc;
+    return (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
   });
-  if (do_stat) stat_flush<BN>(sa, stat, smem, g.Cin, mt, nt, tid);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -750,8 +803,6 @@ __global__ __launch_bounds__(256) void conv_dgrad_fixup_kernel(const float* __re
   const int rt = blockIdx.x, tile = wk.dp_tiles + rt;
   const int mt = tile / NT, nt = tile - mt * NT;
   const int tid = threadIdx.x;
-  const int HW = g.H * g.W;
-  const float rcp_HW = 1.0f / (float)HW;
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   for (int sl = 0; sl < wk.split; ++sl) {
@@ -763,16 +814,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_fixup_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] += src[(size_t)((i * TN + j) * 16 + e) * 256];
   }
-  const bool do_stat = stat.y != nullptr;
-  StatAcc sa;
-  if (do_stat) sa.init(stat, nt * BN + 4 * (tid % (BN / 4)));
-  staged_epilogue<BM, BN, WM, WN>(acc, smem, tid, [&](int tr, int tc, float4 v) {
-    const int row = mt * BM + tr;
-    if (row >= g.M) return;
-    const size_t o = dgrad_store4(dx, add_src, add_mask, g, HW, rcp_HW, row, nt * BN + tc, v);
-    if (do_stat) sa.add(stat, o, v);
-  });
-  if (do_stat) stat_flush<BN>(sa, stat, smem, g.Cin, mt, nt, tid);
+  dgrad_epilogue<BM, BN, WM, WN>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, g.M, stat, [](int mrow) { return mrow; });
 }
 
 // =========================================================================================
