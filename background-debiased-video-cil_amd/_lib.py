@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -28,6 +28,11 @@ class ConvGeom(Structure):
 
 P = c_void_p
 _F3 = c_float * 3
+
+
+class ConvAffine(Structure):
+    """Mirror of ``bdv_conv_affine``."""
+    _fields_ = [('scale', c_void_p), ('shift', c_void_p), ('residual', c_void_p), ('relu', c_int32)]
 
 
 class BnStatFuse(Structure):
@@ -47,7 +52,7 @@ SIGNATURES = {
     'bdv_abi_version': (c_int, []),
     'bdv_conv_workspace_bytes': (c_size_t, [POINTER(ConvGeom), c_int]),
     'bdv_conv_fprop_stat_rows': (c_int, [POINTER(ConvGeom)]),
-    'bdv_conv_fprop': (c_int, [P, P, P, POINTER(ConvGeom), P, P, c_size_t, P]),
+    'bdv_conv_fprop': (c_int, [P, P, P, POINTER(ConvGeom), P, POINTER(ConvAffine), P, c_size_t, P]),
     'bdv_conv_dgrad_stat_rows': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_dgrad': (c_int, [P, P, P, P, P, POINTER(ConvGeom), POINTER(BnStatFuse), P, c_size_t, P]),
     'bdv_conv_wgrad': (c_int, [P, P, P, c_float, POINTER(ConvGeom), POINTER(BnBwdFuse), P, c_size_t, P]),

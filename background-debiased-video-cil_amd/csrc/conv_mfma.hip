@@ -40,6 +40,15 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int vo
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t rsrc, int voff, float4 v) {
+  u32x4 d;
+  d.x = __float_as_uint(v.x);
+  d.y = __float_as_uint(v.y);
+  d.z = __float_as_uint(v.z);
+  d.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, voff, 0, 0);
+}
+
 // q = m / d, r = m % d for 0 <= m < 2^22 with a float reciprocal and one correction step each way
 __device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int& r) {
   q = (int)((float)m * rcp);
@@ -287,14 +296,6 @@ __device__ __forceinline__ void staged_epilogue(const f32x16 (&acc)[BM / WM / 32
 // 16 dependent global-load latencies per tile: the conv1 sites (K loop of 2-16 steps, residual add) ran at half their
 // HBM roofline.
 // rowmap(mrow) -> dx pixel index of tile row mrow (identity for stride 1; parity-class map for stride 2).
-__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t rsrc, int voff, float4 v) {
-  u32x4 d;
-  d.x = __float_as_uint(v.x);
-  d.y = __float_as_uint(v.y);
-  d.z = __float_as_uint(v.z);
-  d.w = __float_as_uint(v.w);
-  __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, voff, 0, 0);
-}
 
 template <int BM, int BN, int WM, int WN, class RowMap>
 __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ smem, int tid,
@@ -425,13 +426,86 @@ __device__ __forceinline__ void tile_colstats(float* __restrict__ smem, float (&
   }
 }
 
+// What the fprop epilogue does besides storing y: BatchNorm batch statistics (training), or -- eval-mode BatchNorm
+// folded into the conv -- out = relu?(acc * scale[c] + shift[c] (+ residual)), which removes the separate
+// bn_apply pass of every inference / frozen-teacher forward.
+struct FpropEpi {
+  float* bn_partial;  // [2][MT][Cout] or null
+  int MT;
+  const float* scale;  // null: plain store
+  const float* shift;
+  const float* res;    // optional residual, same shape as y
+  int relu;
+};
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void fprop_affine_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ smem,
+                                                      float* __restrict__ y, const Geom& g, const FpropEpi& epi, int mt, int nt,
+                                                      int tid) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int V = BN / 4;
+  constexpr int PER = WM * 32 * V / 256;
+  constexpr int HB = PER < 4 ? PER : 4;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn0 = (wave % WN) * 32;
+  const int total_bytes = g.M * g.Cout * 4;
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, total_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(epi.res ? epi.res : y), 0, epi.res ? total_bytes : 0, 0x00020000);
+  const int col = nt * BN + 4 * (tid % V);  // the thread's 4 columns are the same for every piece (256 % V == 0)
+  const float4 sc = *reinterpret_cast<const float4*>(epi.scale + col);
+  const float4 sh = *reinterpret_cast<const float4*>(epi.shift + col);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) smem[(wm * 32 + acc_row(e, lane)) * BN + wn0 + 32 * WN * j + (lane & 31)] = acc[i][j][e];
+    __syncthreads();
+#pragma unroll
+    for (int q0 = 0; q0 < PER; q0 += HB) {  // residual loads of HB pieces in flight (see dgrad_epilogue)
+      float4 v[HB], r[HB];
+      int off[HB];
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+        const int lr = (tid + 256 * (q0 + u)) / V;
+        const int row = mt * BM + 32 * WM * i + lr;
+        off[u] = row < g.M ? (row * g.Cout + col) * 4 : kOOB;
+        v[u] = *reinterpret_cast<const float4*>(smem + lr * BN + 4 * (tid % V));
+        r[u] = buf_load16(rr, off[u], 0);  // zeros without a residual
+      }
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+        float4 o;
+        o.x = v[u].x * sc.x + sh.x + r[u].x;
+        o.y = v[u].y * sc.y + sh.y + r[u].y;
+        o.z = v[u].z * sc.z + sh.z + r[u].z;
+        o.w = v[u].w * sc.w + sh.w + r[u].w;
+        if (epi.relu) {
+          o.x = fmaxf(o.x, 0.f);
+          o.y = fmaxf(o.y, 0.f);
+          o.z = fmaxf(o.z, 0.f);
+          o.w = fmaxf(o.w, 0.f);
+        }
+        buf_store16(yr, off[u], o);
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void fprop_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ smem,
-                                               float* __restrict__ y, const Geom& g, float* __restrict__ bn_partial, int MT,
-                                               int mt, int nt, int tid) {
+                                               float* __restrict__ y, const Geom& g, const FpropEpi& epi, int mt, int nt, int tid) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * 32;
+  if (epi.scale != nullptr) {
+    fprop_affine_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
+    return;
+  }
+  float* const bn_partial = epi.bn_partial;
+  const int MT = epi.MT;
   staged_epilogue<BM, BN, WM, WN>(acc, smem, tid, [&](int tr, int tc, float4 v) {
     const int row = mt * BM + tr;
     if (row < g.M) *reinterpret_cast<float4*>(y + (size_t)row * g.Cout + nt * BN + tc) = v;
@@ -463,7 +537,7 @@ __device__ __forceinline__ void fprop_epilogue(const f32x16 (&acc)[BM / WM / 32]
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 3) void conv_fprop_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           float* __restrict__ y, Geom g, int NT, Work wk,
-                                                          float* __restrict__ slab, float* __restrict__ bn_partial, int MT) {
+                                                          float* __restrict__ slab, FpropEpi epi) {
   constexpr int LDA = BM, LDB = BN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
@@ -554,21 +628,20 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_kernel(const float* __restr
     store_partial<TM, TN>(slab, it.pslot, acc, tid);
     return;
   }
-  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, bn_partial, MT, mt, nt, tid);
+  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
 }
 
 // fprop for the stem (Cin = 4 on NHWC4): one filter tap per 16-byte load, K = R*S*4 padded to a multiple of 32
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             float* __restrict__ y, Geom g, int NT, float* __restrict__ bn_partial,
-                                                             int MT) {
+                                                             float* __restrict__ y, Geom g, int NT, FpropEpi epi) {
   constexpr int LDA = BM, LDB = BN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
   __shared__ __attribute__((aligned(16))) float smem[BK * (LDA + LDB)];
   float* const As = smem;
   float* const Bs = smem + BK * LDA;
-  const int tile = xcd_remap(blockIdx.x, MT * NT);
+  const int tile = xcd_remap(blockIdx.x, epi.MT * NT);
   const int mt = tile / NT, nt = tile - mt * NT;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -618,7 +691,7 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __re
     if (kt + 1 < nk) load(kt + 1);
     mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN, true, true>(As, Bs, acc, wm0, wn0, lane);
   }
-  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, bn_partial, MT, mt, nt, tid);
+  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
 }
 
 // fix-up for the K-split remainder tiles: sum the `split` partial accumulators in slice order, then the same
@@ -626,7 +699,7 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __re
 // main kernel.
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_fprop_fixup_kernel(const float* __restrict__ slab, float* __restrict__ y, Geom g,
-                                                                int NT, Work wk, float* __restrict__ bn_partial, int MT) {
+                                                                int NT, Work wk, FpropEpi epi) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NACC = TM * TN * 16;
   __shared__ __attribute__((aligned(16))) float smem[WM * 32 * BN];
@@ -645,7 +718,7 @@ __global__ __launch_bounds__(256) void conv_fprop_fixup_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] += src[(size_t)((i * TN + j) * 16 + e) * 256];
   }
-  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, bn_partial, MT, mt, nt, tid);
+  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
 }
 
 // =========================================================================================
@@ -1291,9 +1364,20 @@ extern "C" int bdv_conv_fprop_stat_rows(const bdv_conv_geom* gg) {
 }
 
 extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* gg, float* bn_partial,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+                              const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_fprop")) return e;
   BDV_REQUIRE(x && w && y, "bdv_conv_fprop: null pointer");
+  FpropEpi epi = {bn_partial, 0, nullptr, nullptr, nullptr, 0};
+  if (affine != nullptr) {
+    BDV_REQUIRE(bn_partial == nullptr, "bdv_conv_fprop: batch statistics and the folded eval-mode BatchNorm exclude each other");
+    BDV_REQUIRE(affine->scale && affine->shift, "bdv_conv_fprop: null pointer in bdv_conv_affine");
+    BDV_REQUIRE(bdv_aligned16(affine->scale) && bdv_aligned16(affine->shift) && bdv_aligned16(affine->residual),
+                "bdv_conv_fprop: bdv_conv_affine pointers must be 16-byte aligned");
+    epi.scale = affine->scale;
+    epi.shift = affine->shift;
+    epi.res = affine->residual;
+    epi.relu = affine->relu;
+  }
   BDV_REQUIRE(bdv_aligned16(x) && bdv_aligned16(w) && bdv_aligned16(y) && bdv_aligned16(workspace),
               "bdv_conv_fprop: pointers must be 16-byte aligned");
   Geom g = make_geom(gg);
@@ -1303,29 +1387,28 @@ extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bd
   const bool c4 = (g.Cin % BK) != 0;
   const FdPlan p = plan_fprop(g, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0);
   const int blocks = p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split;
+  epi.MT = p.MT;
   float* slab = (float*)workspace;
   if (debug_plan())
     fprintf(stderr, "[bdv plan] fprop %dx%d Cin %d Cout %d k%d s%d: tiles %d nk %d -> dp %d rem %d split %d\n", g.H, g.W,
             g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
   if (c4) {
     if (p.wide)
-      hipLaunchKernelGGL((conv_fprop_c4_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, bn_partial, p.MT);
+      hipLaunchKernelGGL((conv_fprop_c4_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, epi);
     else
-      hipLaunchKernelGGL((conv_fprop_c4_kernel<128, 64, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, bn_partial, p.MT);
+      hipLaunchKernelGGL((conv_fprop_c4_kernel<128, 64, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, epi);
   } else if (p.wide) {
-    hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, bn_partial, p.MT);
+    hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, epi);
   } else {
-    hipLaunchKernelGGL((conv_fprop_kernel<128, 64, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, bn_partial, p.MT);
+    hipLaunchKernelGGL((conv_fprop_kernel<128, 64, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, epi);
   }
   BDV_LAUNCH_CHECK("bdv_conv_fprop");
   if (p.wk.split > 1) {
     const dim3 fg(p.wk.rem_tiles);
     if (p.wide)
-      hipLaunchKernelGGL((conv_fprop_fixup_kernel<128, 128, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk,
-                         bn_partial, p.MT);
+      hipLaunchKernelGGL((conv_fprop_fixup_kernel<128, 128, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk, epi);
     else
-      hipLaunchKernelGGL((conv_fprop_fixup_kernel<128, 64, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk,
-                         bn_partial, p.MT);
+      hipLaunchKernelGGL((conv_fprop_fixup_kernel<128, 64, 2, 2>), fg, dim3(256), 0, s, (const float*)slab, y, g, p.NT, p.wk, epi);
     BDV_LAUNCH_CHECK("bdv_conv_fprop(fixup)");
   }
   return BDV_OK;

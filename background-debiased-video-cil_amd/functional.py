@@ -115,19 +115,22 @@ class UnitSpec:
 
 
 def _conv_bn_forward(x, w_krsc, g, bn, gamma, beta, training):
-    """conv + BatchNorm statistics -> (y, mean, invstd, scale, shift).  In training the batch statistics come out of
-    the conv epilogue (no extra pass over y); running stats are updated in place."""
-    if training:
-        if bn.momentum is None:
-            raise NotImplementedError('BatchNorm momentum=None (cumulative average) is not supported by the HIP path')
-        rm = bn.running_mean if bn.track_running_stats else None
-        rv = bn.running_var if bn.track_running_stats else None
-        y, part = K.conv_fprop(x, w_krsc, g, bn_stats=True)
-        mean, invstd, scale, shift = K.bn_train_finalize(part, g.N * g.Ho * g.Wo, gamma, beta, bn.eps, bn.momentum, rm, rv)
-        return y, mean, invstd, scale, shift
-    y = K.conv_fprop(x, w_krsc, g)
+    """conv + BatchNorm statistics -> (y, mean, invstd, scale, shift) in training mode: the batch statistics come out
+    of the conv epilogue (no extra pass over y) and running stats are updated in place."""
+    if bn.momentum is None:
+        raise NotImplementedError('BatchNorm momentum=None (cumulative average) is not supported by the HIP path')
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    y, part = K.conv_fprop(x, w_krsc, g, bn_stats=True)
+    mean, invstd, scale, shift = K.bn_train_finalize(part, g.N * g.Ho * g.Wo, gamma, beta, bn.eps, bn.momentum, rm, rv)
+    return y, mean, invstd, scale, shift
+
+
+def _conv_bn_eval(x, w_krsc, g, bn, gamma, beta, res, relu):
+    """Eval-mode conv + BatchNorm (+ residual) (+ ReLU) in one kernel: the running statistics fold into a per-channel
+    scale / shift applied in the conv epilogue."""
     scale, shift = K.bn_eval_params(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
-    return y, None, None, scale, shift
+    return K.conv_fprop(x, w_krsc, g, affine=(scale, shift, res, relu))
 
 
 def _bn_wgrad_backward(dout, mask, y, gamma, mean, invstd, inp, geom, need_dw, stat_partial=None):
@@ -153,12 +156,15 @@ class StemFn(torch.autograd.Function):
         g = K.make_geom(N, H, W, 4, weight.shape[0], weight.shape[2], weight.shape[3], 2, weight.shape[2] // 2)
         w4 = torch.zeros((weight.shape[0], weight.shape[2], weight.shape[3], 4), dtype=torch.float32, device=x4.device)
         w4[..., :3] = weight.detach().permute(0, 2, 3, 1)           # 37 KB repack, plumbing
-        y, mean, invstd, scale, shift = _conv_bn_forward(x4, w4, g, bn, gamma, beta, training)
         save = training and any(ctx.needs_input_grad)
-        if save:
-            a, mask = K.bn_apply(y, scale, shift, None, True, want_mask=True)
+        if not training:
+            a, mask, y, mean, invstd = _conv_bn_eval(x4, w4, g, bn, gamma, beta, None, True), None, None, None, None
         else:
-            a, mask = K.bn_apply(y, scale, shift, None, True, out=y), None
+            y, mean, invstd, scale, shift = _conv_bn_forward(x4, w4, g, bn, gamma, beta, training)
+            if save:
+                a, mask = K.bn_apply(y, scale, shift, None, True, want_mask=True)
+            else:
+                a, mask = K.bn_apply(y, scale, shift, None, True, out=y), None
         p, idx = K.maxpool_fwd(a)
         ctx.g = g
         ctx.bn_training = training
@@ -201,8 +207,11 @@ class ResBlockFn(torch.autograd.Function):
             u = units[n_main]
             wd, gd, bd = params[3 * n_main:3 * n_main + 3]
             g = u.geom(N, H, W)
-            yd, mean_d, invstd_d, sc, sh = _conv_bn_forward(x, weight_krsc(wd), g, bns[n_main], gd, bd, training)
-            identity = K.bn_apply(yd, sc, sh, None, False)
+            if training:
+                yd, mean_d, invstd_d, sc, sh = _conv_bn_forward(x, weight_krsc(wd), g, bns[n_main], gd, bd, training)
+                identity = K.bn_apply(yd, sc, sh, None, False)
+            else:
+                identity = _conv_bn_eval(x, weight_krsc(wd), g, bns[n_main], gd, bd, None, False)
         else:
             identity = x
         cur = x
@@ -212,8 +221,12 @@ class ResBlockFn(torch.autograd.Function):
             wt, gm, bt = params[3 * i:3 * i + 3]
             g = u.geom(N, h, w_)
             geoms.append(g)
-            y, mean, invstd, sc, sh = _conv_bn_forward(cur, weight_krsc(wt), g, bns[i], gm, bt, training)
             last = i == n_main - 1
+            if not training:     # eval: conv + folded BatchNorm (+ identity) + ReLU in one kernel
+                cur = _conv_bn_eval(cur, weight_krsc(wt), g, bns[i], gm, bt, identity if last else None, True)
+                h, w_ = g.Ho, g.Wo
+                continue
+            y, mean, invstd, sc, sh = _conv_bn_forward(cur, weight_krsc(wt), g, bns[i], gm, bt, training)
             if save:
                 a, mask = K.bn_apply(y, sc, sh, identity if last else None, True, want_mask=True)
                 saved += [y, a, mean, invstd, mask]

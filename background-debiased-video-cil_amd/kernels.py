@@ -11,7 +11,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from ._lib import BnBwdFuse, BnStatFuse, ConvGeom, check, lib
+from ._lib import BnBwdFuse, BnStatFuse, ConvAffine, ConvGeom, check, lib
 
 _WS = {}  # (device index, tag) -> workspace tensor (grown on demand, never shrunk)
 
@@ -65,22 +65,33 @@ def _conv_ws(g: ConvGeom, kind: int, device, tag: str) -> torch.Tensor:
 
 
 def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torch.Tensor] = None,
-               ws_tag: str = 'conv', bn_stats: bool = False):
+               ws_tag: str = 'conv', bn_stats: bool = False, affine=None):
     """x (N,H,W,Cin) NHWC, w (Cout,R,S,Cin) -> y (N,Ho,Wo,Cout); with bn_stats also the fused BatchNorm partial
-    sums (float[2][rows][Cout]) for ``bn_train_finalize``."""
+    sums (float[2][rows][Cout]) for ``bn_train_finalize``.
+    ``affine = (scale, shift, residual | None, relu)``: eval-mode BatchNorm folded into the epilogue,
+    y = relu?(conv * scale + shift (+ residual))."""
     _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
     _chk(w, (g.Cout, g.R, g.S, g.Cin), name='w')
     y = out if out is not None else torch.empty((g.N, g.Ho, g.Wo, g.Cout), dtype=torch.float32, device=x.device)
     _chk(y, (g.N, g.Ho, g.Wo, g.Cout), name='y')
     ws = _conv_ws(g, 0, x.device, ws_tag)
-    part = None
+    part = aff = None
     if bn_stats:
+        if affine is not None:
+            raise ValueError('conv_fprop: bn_stats and affine exclude each other')
         rows = lib().bdv_conv_fprop_stat_rows(ctypes.byref(g))
         if rows <= 0:
             check(-1, 'bdv_conv_fprop_stat_rows')
         part = torch.empty((2, rows, g.Cout), dtype=torch.float32, device=x.device)
-    check(lib().bdv_conv_fprop(_p(x), _p(w), _p(y), ctypes.byref(g), _p(part), _p(ws), ws.numel(), _stream()),
-          'bdv_conv_fprop')
+    if affine is not None:
+        scale, shift, res, relu = affine
+        _chk(scale, (g.Cout,), name='scale')
+        _chk(shift, (g.Cout,), name='shift')
+        if res is not None:
+            _chk(res, (g.N, g.Ho, g.Wo, g.Cout), name='residual')
+        aff = ConvAffine(scale.data_ptr(), shift.data_ptr(), res.data_ptr() if res is not None else None, int(bool(relu)))
+    check(lib().bdv_conv_fprop(_p(x), _p(w), _p(y), ctypes.byref(g), _p(part), ctypes.byref(aff) if aff is not None else None,
+                               _p(ws), ws.numel(), _stream()), 'bdv_conv_fprop')
     return (y, part) if bn_stats else y
 
 

@@ -61,8 +61,17 @@ size_t bdv_conv_workspace_bytes(const bdv_conv_geom* g, int kind);
  * writes per-row-tile column sums of y and y*y (the BatchNorm batch statistics, fused: y is not re-read);
  * bdv_bn_train_finalize reduces them in fixed order. */
 int bdv_conv_fprop_stat_rows(const bdv_conv_geom* g);
-int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* g, float* bn_partial, void* workspace,
-                   size_t workspace_bytes, void* stream);
+/* affine (optional, excludes bn_partial): eval-mode BatchNorm folded into the epilogue,
+ * y = relu?(conv * scale[c] + shift[c] (+ residual)) with scale/shift from bdv_bn_eval_params: the inference and
+ * frozen-teacher forwards (UPSTREAM Recognizer2D._do_test, libs/cil/cil.py:520-522) then have no bn_apply pass. */
+typedef struct bdv_conv_affine {
+  const float* scale;    /* [Cout] */
+  const float* shift;    /* [Cout] */
+  const float* residual; /* [N,Ho,Wo,Cout] or NULL */
+  int32_t relu;
+} bdv_conv_affine;
+int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* g, float* bn_partial,
+                   const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream);
 
 /* BatchNorm(+ReLU) backward "apply" step fused into wgrad: instead of a materialised dy the wgrad kernel reads
  * the gradient w.r.t. the BN/ReLU output, the ReLU sign mask, the saved conv output and the coefficients written

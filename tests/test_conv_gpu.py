@@ -280,3 +280,25 @@ def test_dgrad_fused_bn_backward_statistics(case, relu, dev):
         _close(u, v, tol=2e-5)
     with pytest.raises(Exception):
         K.conv_dgrad(dy, wd, K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, 8, 8), bn_stats=(yprev, mask, mean, invstd))
+
+
+@pytest.mark.parametrize('case', [CASES[0], CASES[2], CASES[5], CASES[8], CASES[11], (64, 14, 14, 256, 256, 3, 1, 1, 1, 0)])
+@pytest.mark.parametrize('res,relu', [(False, True), (True, True), (False, False)])
+def test_fprop_folded_eval_batchnorm(case, res, relu, dev):
+    """Eval-mode BatchNorm (+ residual) (+ ReLU) folded into the fprop epilogue == conv followed by bn_apply."""
+    from bdvcil_amd import kernels as K
+    N, H, W, Cin, Cout, R, st, pad, T, fold = case
+    x, w = _mk(case, 8)
+    gen = torch.Generator().manual_seed(41)
+    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    scale = (torch.rand(Cout, generator=gen) + 0.5).to(dev)
+    shift = torch.randn(Cout, generator=gen).to(dev)
+    r = torch.randn(N, g.Ho, g.Wo, Cout, generator=gen).to(dev) if res else None
+    ref = K.bn_apply(K.conv_fprop(xd, wd, g), scale, shift, r, relu)
+    out = K.conv_fprop(xd, wd, g, affine=(scale, shift, r, relu))
+    torch.cuda.synchronize()
+    _close(out, ref, tol=1e-6)
+    with pytest.raises(ValueError):
+        K.conv_fprop(xd, wd, g, bn_stats=True, affine=(scale, shift, r, relu))
