@@ -26,6 +26,7 @@ import torch.distributed as dist  # noqa: E402
 
 R50_FLOP_PER_CLIP = 194.29e9       # BASELINE.md section 2 (fwd+bwd, conv MACs only, stem dgrad excluded)
 R50_KD_FLOP_PER_CLIP = 259.7e9     # + the frozen previous model's forward
+R50_FWD_FLOP_PER_CLIP = 65.39e9    # forward only (2 x 8 x 4.0871 GMAC)
 PEAK_F32_MFMA = 157.3e12           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 
 
@@ -151,9 +152,10 @@ def main():
     ap.add_argument('--head', default='SimpleLinear', choices=['SimpleLinear', 'LocalSimilarityClassifier'])
     ap.add_argument('--loss', default='CrossEntropyLoss', choices=['CrossEntropyLoss', 'LSCLoss'])
     ap.add_argument('--dropout', type=float, default=0.5)
-    ap.add_argument('--workload', default='ce', choices=['ce', 'cil'],
+    ap.add_argument('--workload', default='ce', choices=['ce', 'cil', 'predict'],
                     help="'ce': BASELINE config 2 (the metric); 'cil': config 3 step = uint8 background-mix front-end, LSC head + "
-                         "LSCLoss, feature-KD against a frozen previous model (task >= 1), clip 1.0, SGD")
+                         "LSCLoss, feature-KD against a frozen previous model (task >= 1), clip 1.0, SGD; 'predict': eval forward "
+                         "+ representations of BaseCIL.predict_step (SURVEY section 8(f) rank 1), no backward")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -179,7 +181,8 @@ def main():
         timer.wrap(K)
 
     cil = args.workload == 'cil'
-    if cil:
+    predict = args.workload == 'predict'
+    if cil or predict:
         args.head, args.loss = 'LocalSimilarityClassifier', 'LSCLoss'
     torch.manual_seed(0)
     model = bd.build_model(model_cfg(args.depth, args.classes, args.head, args.loss, args.dropout)).to(dev)
@@ -191,6 +194,15 @@ def main():
     opt = bd.build_optimizer(model, dict(type='SGD', constructor='CILTSMOptimizerConstructorImprovised',
                                          paramwise_cfg=dict(fc_lr_scale_factor=5.0), lr=0.01, momentum=0.9, weight_decay=1e-4))
     engine = bd.TrainEngine(model, opt, grad_clip=1.0 if cil else None, reducer=reducer)
+    if predict:
+        model.eval()
+        predictor = bd.ReprPredictor(model)
+
+        class _Predict:                       # same interface as TrainEngine.step for the timing loop below
+            def step(self, b, _loss_fn=None):
+                r = predictor.predict_step(b)
+                return {'loss_cls': r['cls_score'].sum() * 0.0, 'repr_': r['repr_']}
+        engine = _Predict()
 
     g = torch.Generator().manual_seed(1000 + rank)
     labels = torch.randint(0, args.classes, (args.batch, 1), generator=g).to(dev)
@@ -245,10 +257,11 @@ def main():
     if rank == 0:
         clips = args.batch * world * args.steps
         value = clips / dt
-        flop_per_clip = (R50_KD_FLOP_PER_CLIP if cil else R50_FLOP_PER_CLIP) if args.depth == 50 else None
+        flop_per_clip = (R50_KD_FLOP_PER_CLIP if cil else R50_FWD_FLOP_PER_CLIP if predict else R50_FLOP_PER_CLIP) if args.depth == 50 else None
         res = {
             'metric': ('clips/sec fwd+bwd TSM-R50 8x224^2 bs32/GPU' if args.depth == 50 else f'clips/sec fwd+bwd TSM-R{args.depth}')
-                      + (' (CIL step: bg-mix front-end + KD teacher + LSCLoss)' if cil else ''),
+                      + (' (CIL step: bg-mix front-end + KD teacher + LSCLoss)' if cil else '')
+                      + (' (predict_step: eval forward + representations, no backward)' if predict else ''),
             'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000.0 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -283,7 +296,7 @@ def main():
                 'conv_ms_per_step': round(tot_ms / timed_steps, 3), 'conv_tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                 'kernel_timed_steps': timed_steps,
             }
-        if world == 1 and not args.no_cpu_baseline and not cil:
+        if world == 1 and not args.no_cpu_baseline and not cil and not predict:
             res['cpu_baseline'] = cpu_baseline(args.depth, args.classes, args.head, args.loss)
         print(json.dumps(res), flush=True)
     if world > 1:
