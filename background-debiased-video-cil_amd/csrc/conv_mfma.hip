@@ -209,9 +209,10 @@ __device__ __forceinline__ void fprop_store(float* __restrict__ y, const Geom& g
 
 // BatchNorm-backward statistics of the tensor a dgrad produces, taken in its epilogue (bdv_bn_stat_fuse): the dx a
 // thread stores is the gradient w.r.t. the BN(+ReLU) output of the previous conv unit, so  sum(g)  and  sum(g * xhat)
-// (g = dx * mask, xhat = (y - mean) * invstd) are accumulated per thread over its rows (a thread keeps the same 4
-// columns in every pass of the staged epilogue), reduced over the tile in fixed order and written to
-// partial[0 | 1][mt][Cin]; the separate statistics pass over dx, y and the mask disappears.
+// (g = dx * mask, xhat = (y - mean) * invstd) are accumulated per thread over the pieces it stores (a thread keeps the
+// same 4 columns in every pass of the staged epilogue; with a temporal shift a piece lands in another frame, and y /
+// mask are read at that destination: every dx element is still written exactly once), reduced over the tile in fixed
+// order and written to partial[0 | 1][mt][Cin]; the separate statistics pass over dx, y and the mask disappears.
 struct BnStat {
   const float* y;
   const uint32_t* mask;  // may be null (no ReLU)
@@ -1426,8 +1427,7 @@ extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const 
   if (int e = check_geom(gg, "bdv_conv_dgrad")) return e;
   BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   if (bn_stat != nullptr) {
-    BDV_REQUIRE(gg->stride == 1 && gg->fold == 0,
-                "bdv_conv_dgrad: fused BatchNorm statistics need stride 1 and no temporal shift (dx rows map one to one)");
+    BDV_REQUIRE(gg->stride == 1, "bdv_conv_dgrad: fused BatchNorm statistics need stride 1");
     BDV_REQUIRE(bn_stat->y && bn_stat->mean && bn_stat->invstd && bn_stat->partial, "bdv_conv_dgrad: null pointer in bdv_bn_stat_fuse");
     BDV_REQUIRE(bdv_aligned16(bn_stat->y) && bdv_aligned16(bn_stat->mean) && bdv_aligned16(bn_stat->invstd) &&
                     bdv_aligned16(bn_stat->partial), "bdv_conv_dgrad: bdv_bn_stat_fuse pointers must be 16-byte aligned");

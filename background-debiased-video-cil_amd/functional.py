@@ -43,6 +43,8 @@ FUSE_BN_BWD = _os.environ.get('BDVCIL_FUSE_BN_BWD', '0') != '0'
 # BatchNorm-backward statistics of a unit taken in the epilogue of the dgrad that produces its output gradient
 # (bdv_conv_dgrad with a bdv_bn_stat_fuse): removes the separate pass over dout, y and the mask for the inner units.
 FUSE_BN_STATS = _os.environ.get('BDVCIL_FUSE_BN_STATS', '1') != '0'
+# A whole stage as one autograd node (ResStageFn): lets the statistics fusion above reach the block outputs.
+FUSE_STAGE = _os.environ.get('BDVCIL_FUSE_STAGE', '1') != '0'
 
 
 def set_side_stream_enabled(flag: bool):
@@ -189,120 +191,204 @@ class StemFn(torch.autograd.Function):
         return None, dw, dgamma, dbeta, None, None
 
 
+def _block_forward(x, blk, training, params, save):
+    """Forward of one residual block (UPSTREAM BasicBlock / Bottleneck, shift_place='blockres') on NHWC storage.
+    Returns (out, saved tensors for backward, geoms)."""
+    units: List[UnitSpec] = blk.unit_specs
+    bns = blk.unit_bns
+    n_main = blk.n_main
+    has_down = len(units) > n_main
+    N, H, W, _ = x.shape
+    saved = [x]
+    geoms = []
+    # identity path
+    if has_down:
+        u = units[n_main]
+        wd, gd, bd = params[3 * n_main:3 * n_main + 3]
+        g = u.geom(N, H, W)
+        if training:
+            yd, mean_d, invstd_d, sc, sh = _conv_bn_forward(x, weight_krsc(wd), g, bns[n_main], gd, bd, training)
+            identity = K.bn_apply(yd, sc, sh, None, False)
+        else:
+            identity = _conv_bn_eval(x, weight_krsc(wd), g, bns[n_main], gd, bd, None, False)
+    else:
+        identity = x
+    cur = x
+    h, w_ = H, W
+    for i in range(n_main):
+        u = units[i]
+        wt, gm, bt = params[3 * i:3 * i + 3]
+        g = u.geom(N, h, w_)
+        geoms.append(g)
+        last = i == n_main - 1
+        if not training:     # eval: conv + folded BatchNorm (+ identity) + ReLU in one kernel
+            cur = _conv_bn_eval(cur, weight_krsc(wt), g, bns[i], gm, bt, identity if last else None, True)
+            h, w_ = g.Ho, g.Wo
+            continue
+        y, mean, invstd, sc, sh = _conv_bn_forward(cur, weight_krsc(wt), g, bns[i], gm, bt, training)
+        if save:
+            a, mask = K.bn_apply(y, sc, sh, identity if last else None, True, want_mask=True)
+            saved += [y, a, mean, invstd, mask]
+        else:
+            a = K.bn_apply(y, sc, sh, identity if last else None, True)
+        cur = a
+        h, w_ = g.Ho, g.Wo
+    if save and has_down:
+        saved += [yd, mean_d, invstd_d]
+        geoms.append(units[n_main].geom(N, H, W))
+    return cur, (saved if save else []), geoms
+
+
+def _block_out_stats(saved, n_main):
+    """(y, mask, mean, invstd) of a block's last main unit: what a dgrad epilogue needs to take the BatchNorm-backward
+    statistics of the gradient it writes into that block's output."""
+    k = n_main - 1
+    return saved[1 + 5 * k], saved[5 + 5 * k], saved[3 + 5 * k], saved[4 + 5 * k]
+
+
+def _block_backward(saved, params, geoms, n_main, has_down, dout, need_params, need_dx, out_stat_partial=None,
+                    prev_stats=None):
+    """Backward of one residual block.  ``out_stat_partial``: tile sums of the BatchNorm-backward statistics of ``dout``
+    against this block's last unit, when the producer of ``dout`` already took them.  ``prev_stats``: statistics
+    operands of the PREVIOUS block's last unit; the dgrad that writes dx then reduces them in its epilogue.
+    Returns (dx, parameter gradients, partial for the previous block | None)."""
+    x = saved[0]
+    ys = [saved[1 + 5 * i] for i in range(n_main)]
+    acts = [saved[2 + 5 * i] for i in range(n_main)]
+    means = [saved[3 + 5 * i] for i in range(n_main)]
+    invstds = [saved[4 + 5 * i] for i in range(n_main)]
+    masks = [saved[5 + 5 * i] for i in range(n_main)]
+    out_mask = masks[-1]
+    dout = dout if dout.is_contiguous() else dout.contiguous()
+    grads: List[Optional[torch.Tensor]] = [None] * len(params)
+
+    # main branch, last unit first.  ``d`` is the gradient w.r.t. the unit's (post-ReLU) output.
+    d, part = dout, out_stat_partial
+    for i in range(n_main - 1, -1, -1):
+        wt, gm = params[3 * i], params[3 * i + 1]
+        inp = acts[i - 1] if i > 0 else x
+        dy, dg, db, dw = _bn_wgrad_backward(d, masks[i], ys[i], gm, means[i], invstds[i], inp, geoms[i], need_params[3 * i],
+                                            stat_partial=part)
+        grads[3 * i + 1], grads[3 * i + 2] = dg, db
+        if dw is not None:
+            grads[3 * i] = dw.permute(0, 3, 1, 2)
+        part = None
+        if i > 0:
+            gi = geoms[i]
+            if FUSE_BN_STATS and gi.stride == 1:
+                # this dgrad produces the gradient entering unit i-1's BN+ReLU: take its statistics in the epilogue
+                d, part = K.conv_dgrad(dy, weight_krsc(wt), gi, bn_stats=(ys[i - 1], masks[i - 1], means[i - 1], invstds[i - 1]))
+            else:
+                d = K.conv_dgrad(dy, weight_krsc(wt), gi)
+        else:
+            dy_first = dy
+
+    dx, prev_partial = None, None
+    stats = prev_stats if (FUSE_BN_STATS and prev_stats is not None and geoms[0].stride == 1) else None
+    if has_down:
+        yd, mean_d, invstd_d = saved[1 + 5 * n_main:4 + 5 * n_main]
+        wd, gd = params[3 * n_main], params[3 * n_main + 1]
+        gdn = geoms[n_main]
+        # gradient entering the downsample BN is dout * (out > 0): same mask as the block output
+        dyd, dgd, dbd, dwd = _bn_wgrad_backward(dout, out_mask, yd, gd, mean_d, invstd_d, x, gdn, need_params[3 * n_main])
+        grads[3 * n_main + 1], grads[3 * n_main + 2] = dgd, dbd
+        if dwd is not None:
+            grads[3 * n_main] = dwd.permute(0, 3, 1, 2)
+        if need_dx:
+            dx_id = K.conv_dgrad(dyd, weight_krsc(wd), gdn)
+            dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), geoms[0], add_src=dx_id, bn_stats=stats)
+    elif need_dx:
+        # identity path: dout * (out > 0), fused into the conv1 dgrad epilogue
+        dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), geoms[0], add_src=dout, add_mask_src=out_mask, bn_stats=stats)
+    if stats is not None and dx is not None:
+        dx, prev_partial = dx
+    return dx, grads, prev_partial
+
+
+_EVAL_BN_BACKWARD = 'backward through eval-mode BatchNorm is not implemented (norm_eval=False in all CIL configs)'
+
+
 class ResBlockFn(torch.autograd.Function):
-    """One residual block (UPSTREAM BasicBlock / Bottleneck, shift_place='blockres')."""
+    """One residual block as an autograd node (used when a stage cannot run as one node, e.g. hooks on its blocks)."""
 
     @staticmethod
     def forward(ctx, x, blk, training, *params):
-        units: List[UnitSpec] = blk.unit_specs
-        bns = blk.unit_bns
-        n_main = blk.n_main
-        has_down = len(units) > n_main
-        N, H, W, _ = x.shape
         save = training and any(ctx.needs_input_grad)
-        saved = [x]
-        geoms = []
-        # identity path
-        if has_down:
-            u = units[n_main]
-            wd, gd, bd = params[3 * n_main:3 * n_main + 3]
-            g = u.geom(N, H, W)
-            if training:
-                yd, mean_d, invstd_d, sc, sh = _conv_bn_forward(x, weight_krsc(wd), g, bns[n_main], gd, bd, training)
-                identity = K.bn_apply(yd, sc, sh, None, False)
-            else:
-                identity = _conv_bn_eval(x, weight_krsc(wd), g, bns[n_main], gd, bd, None, False)
-        else:
-            identity = x
-        cur = x
-        h, w_ = H, W
-        for i in range(n_main):
-            u = units[i]
-            wt, gm, bt = params[3 * i:3 * i + 3]
-            g = u.geom(N, h, w_)
-            geoms.append(g)
-            last = i == n_main - 1
-            if not training:     # eval: conv + folded BatchNorm (+ identity) + ReLU in one kernel
-                cur = _conv_bn_eval(cur, weight_krsc(wt), g, bns[i], gm, bt, identity if last else None, True)
-                h, w_ = g.Ho, g.Wo
-                continue
-            y, mean, invstd, sc, sh = _conv_bn_forward(cur, weight_krsc(wt), g, bns[i], gm, bt, training)
-            if save:
-                a, mask = K.bn_apply(y, sc, sh, identity if last else None, True, want_mask=True)
-                saved += [y, a, mean, invstd, mask]
-            else:
-                a = K.bn_apply(y, sc, sh, identity if last else None, True)
-            cur = a
-            h, w_ = g.Ho, g.Wo
+        out, saved, geoms = _block_forward(x, blk, training, params, save)
         if save:
-            if has_down:
-                saved += [yd, mean_d, invstd_d]
-                geoms.append(units[n_main].geom(N, H, W))
             ctx.save_for_backward(*saved, *params)
             ctx.n_saved = len(saved)
         ctx.geoms = geoms
-        ctx.n_main = n_main
-        ctx.has_down = has_down
+        ctx.n_main = blk.n_main
+        ctx.has_down = len(blk.unit_specs) > blk.n_main
+        ctx.bn_training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.bn_training:
+            raise NotImplementedError(_EVAL_BN_BACKWARD)
+        t = ctx.saved_tensors
+        saved, params = t[:ctx.n_saved], t[ctx.n_saved:]
+        need = ctx.needs_input_grad      # (x, blk, training, *params)
+        dx, grads, _ = _block_backward(saved, params, ctx.geoms, ctx.n_main, ctx.has_down, dout, need[3:], need[0])
+        return (dx, None, None, *grads)
+
+
+class ResStageFn(torch.autograd.Function):
+    """A whole stage (UPSTREAM ResNet.layerN = a sequence of residual blocks) as ONE autograd node.  The tensors
+    between its blocks are then private to this node (exactly one producer and one consumer), which is what allows
+    block k+1's conv1 dgrad -- the kernel that writes the gradient w.r.t. block k's output -- to take the
+    BatchNorm-backward statistics of block k's last unit in its epilogue instead of a separate pass over that
+    (widest) tensor.  Arithmetic per block is that of ResBlockFn."""
+
+    @staticmethod
+    def forward(ctx, x, blocks, training, *params):
+        save = training and any(ctx.needs_input_grad)
+        cur, off = x, 0
+        all_saved, meta = [], []
+        for blk in blocks:
+            npar = 3 * len(blk.unit_specs)
+            out, saved, geoms = _block_forward(cur, blk, training, params[off:off + npar], save)
+            meta.append((len(saved), npar, geoms, blk.n_main, len(blk.unit_specs) > blk.n_main))
+            all_saved += saved
+            off += npar
+            cur = out
+        if save:
+            ctx.save_for_backward(*all_saved, *params)
+        ctx.meta = meta
         ctx.bn_training = training
         return cur
 
     @staticmethod
     def backward(ctx, dout):
         if not ctx.bn_training:
-            raise NotImplementedError('backward through eval-mode BatchNorm is not implemented (norm_eval=False in all CIL configs)')
+            raise NotImplementedError(_EVAL_BN_BACKWARD)
         t = ctx.saved_tensors
-        saved, params = t[:ctx.n_saved], t[ctx.n_saved:]
-        n_main, has_down = ctx.n_main, ctx.has_down
-        x = saved[0]
-        ys = [saved[1 + 5 * i] for i in range(n_main)]
-        acts = [saved[2 + 5 * i] for i in range(n_main)]
-        means = [saved[3 + 5 * i] for i in range(n_main)]
-        invstds = [saved[4 + 5 * i] for i in range(n_main)]
-        masks = [saved[5 + 5 * i] for i in range(n_main)]
-        out_mask = masks[-1]
-        dout = dout if dout.is_contiguous() else dout.contiguous()
-        need = ctx.needs_input_grad      # (x, blk, training, *params)
-        grads: List[Optional[torch.Tensor]] = [None] * len(params)
-        need_dx = need[0]
-
-        # main branch, last unit first.  ``d`` is the gradient w.r.t. the unit's (post-ReLU) output.
+        meta = ctx.meta
+        n_saved_total = sum(m[0] for m in meta)
+        saved_all, params_all = t[:n_saved_total], t[n_saved_total:]
+        need = ctx.needs_input_grad      # (x, blocks, training, *params)
+        s_off = [0]
+        p_off = [0]
+        for m in meta:
+            s_off.append(s_off[-1] + m[0])
+            p_off.append(p_off[-1] + m[1])
+        grads_all: List[Optional[torch.Tensor]] = [None] * len(params_all)
         d, part = dout, None
-        for i in range(n_main - 1, -1, -1):
-            wt, gm = params[3 * i], params[3 * i + 1]
-            inp = acts[i - 1] if i > 0 else x
-            dy, dg, db, dw = _bn_wgrad_backward(d, masks[i], ys[i], gm, means[i], invstds[i], inp, ctx.geoms[i],
-                                                need[3 + 3 * i], stat_partial=part)
-            grads[3 * i + 1], grads[3 * i + 2] = dg, db
-            if dw is not None:
-                grads[3 * i] = dw.permute(0, 3, 1, 2)
-            part = None
-            if i > 0:
-                gi = ctx.geoms[i]
-                if FUSE_BN_STATS and gi.stride == 1 and gi.fold == 0:
-                    # this dgrad produces the gradient entering unit i-1's BN+ReLU: take its statistics in the epilogue
-                    d, part = K.conv_dgrad(dy, weight_krsc(wt), gi, bn_stats=(ys[i - 1], masks[i - 1], means[i - 1], invstds[i - 1]))
-                else:
-                    d = K.conv_dgrad(dy, weight_krsc(wt), gi)
-            else:
-                dy_first = dy
-
-        dx = None
-        if has_down:
-            yd, mean_d, invstd_d = saved[1 + 5 * n_main:4 + 5 * n_main]
-            wd, gd = params[3 * n_main], params[3 * n_main + 1]
-            gdn = ctx.geoms[n_main]
-            # gradient entering the downsample BN is dout * (out > 0): same mask as the block output
-            dyd, dgd, dbd, dwd = _bn_wgrad_backward(dout, out_mask, yd, gd, mean_d, invstd_d, x, gdn, need[3 + 3 * n_main])
-            grads[3 * n_main + 1], grads[3 * n_main + 2] = dgd, dbd
-            if dwd is not None:
-                grads[3 * n_main] = dwd.permute(0, 3, 1, 2)
-            if need_dx:
-                dx_id = K.conv_dgrad(dyd, weight_krsc(wd), gdn)
-                dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), ctx.geoms[0], add_src=dx_id)
-        elif need_dx:
-            # identity path: dout * (out > 0), fused into the conv1 dgrad epilogue
-            dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), ctx.geoms[0], add_src=dout, add_mask_src=out_mask)
-        return (dx, None, None, *grads)
+        for k in range(len(meta) - 1, -1, -1):
+            n_saved, npar, geoms, n_main, has_down = meta[k]
+            saved = saved_all[s_off[k]:s_off[k + 1]]
+            params = params_all[p_off[k]:p_off[k + 1]]
+            prev_stats = None
+            if k > 0:
+                pm = meta[k - 1]
+                prev_stats = _block_out_stats(saved_all[s_off[k - 1]:s_off[k]], pm[3])
+            need_dx = need[0] or k > 0
+            d, grads, part = _block_backward(saved, params, geoms, n_main, has_down, d, need[3 + p_off[k]:3 + p_off[k + 1]],
+                                             need_dx, out_stat_partial=part, prev_stats=prev_stats)
+            grads_all[p_off[k]:p_off[k + 1]] = grads
+        return (d, None, None, *grads_all)
 
 
 class AvgPoolFn(torch.autograd.Function):

@@ -139,6 +139,36 @@ class _ResBlock(nn.Module):
         return Fn.nhwc_to_nchw_view(out)
 
 
+class ResStage(nn.Sequential):
+    """UPSTREAM ``ResNet.layerN``: the blocks of one stage.  Same module tree and ``state_dict`` keys as an
+    ``nn.Sequential``; the forward runs the stage as one autograd node (``ResStageFn``) so that kernels can fuse across
+    block boundaries.  If anything hooks an individual block (forward / pre-forward / backward hooks) the stage falls back
+    to block-by-block execution, where every block output is a regular autograd tensor."""
+
+    def _blocks_are_plain(self):
+        for b in self:
+            if not isinstance(b, _ResBlock):
+                return False
+            if b._forward_hooks or b._forward_pre_hooks or b._backward_hooks or getattr(b, '_backward_pre_hooks', None):
+                return False
+        return True
+
+    def forward(self, x):
+        if not Fn.FUSE_STAGE or len(self) < 2 or not self._blocks_are_plain():
+            return super().forward(x)
+        xh = Fn.nchw_view_to_nhwc(x)
+        blocks = list(self)
+        params = []
+        for b in blocks:
+            for m in b.unit_modules:
+                params += [m.raw_conv.weight, m.bn.weight, m.bn.bias]
+        flags = {b.unit_bns[0].training for b in blocks}
+        if len(flags) != 1:
+            return super().forward(x)
+        out = Fn.ResStageFn.apply(xh, blocks, flags.pop(), *params)
+        return Fn.nhwc_to_nchw_view(out)
+
+
 class BasicBlock(_ResBlock):
     expansion = 1
     main_names = ['conv1', 'conv2']
@@ -197,7 +227,7 @@ class ResNetTSM(nn.Module):
                 blocks.append(block(inplanes, planes, s, down))
                 inplanes = planes * block.expansion
             name = f'layer{i + 1}'
-            setattr(self, name, nn.Sequential(*blocks))
+            setattr(self, name, ResStage(*blocks))
             self.res_layers.append(name)
         self.feat_dim = inplanes
         self._shift_made = False

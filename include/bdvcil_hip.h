@@ -88,7 +88,7 @@ typedef struct bdv_bn_bwd_fuse {
 /* BatchNorm-backward statistics fused into dgrad: dx (the gradient w.r.t. the BN(+ReLU) output of the PREVIOUS conv unit,
  * whose saved conv output is y) is reduced in the dgrad epilogue to partial[0][r][c] = sum(g), partial[1][r][c] =
  * sum(g * xhat) per 128-row tile r (g = dx * mask, xhat = (y - mean) * invstd; rows = bdv_conv_dgrad_stat_rows(g));
- * bdv_bn_backward(stat_partial = ...) then skips its own statistics pass.  Needs stride 1 and fold 0. */
+ * bdv_bn_backward(stat_partial = ...) then skips its own statistics pass.  Needs stride 1. */
 typedef struct bdv_bn_stat_fuse {
   const float* y;            /* [N,H,W,Cin] conv output of the previous unit */
   const uint32_t* relu_mask; /* 1 bit per element of dx, or NULL (no ReLU) */

@@ -240,6 +240,8 @@ STAT_CASES = [
     (2, 9, 9, 128, 128, 3, 1, 1, 1, 0),       # 3x3
     (64, 14, 14, 256, 256, 3, 1, 1, 1, 0),    # 98 x 2 = 196 tiles: one partial round, K-split fix-up path
     (8, 7, 7, 256, 512, 3, 1, 1, 1, 0),
+    (16, 7, 7, 256, 128, 1, 1, 0, 8, 32),     # conv1 of a bottleneck: temporal shift (pieces land in other frames) + residual
+    (16, 6, 6, 64, 64, 3, 1, 1, 8, 8),        # BasicBlock conv1 with shift, 128x64 tiles
 ]
 
 
@@ -260,8 +262,9 @@ def test_dgrad_fused_bn_backward_statistics(case, relu, dev):
     mask = None
     if relu:
         _, mask = K.bn_apply(yprev, scale, shift, None, True, want_mask=True)
-    dx_ref = K.conv_dgrad(dy, wd, g)
-    dx, part = K.conv_dgrad(dy, wd, g, bn_stats=(yprev, mask, mean, invstd))
+    add = torch.randn(N, H, W, Cin, generator=gen).to(dev) if fold > 0 else None      # residual path of the block
+    dx_ref = K.conv_dgrad(dy, wd, g, add_src=add)
+    dx, part = K.conv_dgrad(dy, wd, g, add_src=add, bn_stats=(yprev, mask, mean, invstd))
     torch.cuda.synchronize()
     assert torch.equal(dx, dx_ref)
     assert part.shape == (2, (N * H * W + 127) // 128, Cin)
@@ -278,8 +281,11 @@ def test_dgrad_fused_bn_backward_statistics(case, relu, dev):
     b = K.bn_backward(dx_ref, mask, yprev, gamma, mean, invstd, relu, stat_partial=part)
     for u, v in zip(a, b):
         _close(u, v, tol=2e-5)
-    with pytest.raises(Exception):
-        K.conv_dgrad(dy, wd, K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, 8, 8), bn_stats=(yprev, mask, mean, invstd))
+    if R == 3:      # stride 2 (parity classes) cannot carry the statistics
+        g2 = K.make_geom(N, H, W, Cin, Cout, R, R, 2, pad, T, fold)
+        dy2 = torch.randn(N, g2.Ho, g2.Wo, Cout, generator=gen).to(dev)
+        with pytest.raises(Exception):
+            K.conv_dgrad(dy2, wd, g2, bn_stats=(yprev, mask, mean, invstd))
 
 
 @pytest.mark.parametrize('case', [CASES[0], CASES[2], CASES[5], CASES[8], CASES[11], (64, 14, 14, 256, 256, 3, 1, 1, 1, 0)])

@@ -43,7 +43,7 @@ def _rel(a, b):
 def _rel_l2(a, b):
     """Relative L2 error.  Used for gradients: train-mode BN + ReLU masks (and max-pool arg-max) are
     discontinuous, so a handful of activations within ~1e-6 of zero take different branches in any two fp32
-    implementations (the fp32 CPU oracle differs from its own fp64 run in the same way, tools/debug_grads.py);
+    implementations (the fp32 CPU oracle differs from its own fp64 run in the same way);
     each flip perturbs one channel's gradient by a few per cent of its scale.  A max-abs bar would measure
     those rare flips, not the kernels; the kernels themselves are held to 2e-5 in test_conv_gpu / test_ops_gpu."""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
@@ -239,3 +239,37 @@ def test_multi_step_training_tracks_the_oracle(dev):
     assert hip_curve[-1] < hip_curve[0]
     for a, b in zip(hip_curve, ref_curve):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (hip_curve, ref_curve)
+
+
+def test_stage_node_matches_block_nodes(dev):
+    """A stage run as one autograd node (statistics of the block outputs taken in the next block's dgrad epilogue) gives
+    the gradients of the block-by-block execution; a hook on an inner block switches the stage back automatically."""
+    import bdvcil_amd as bd
+    from bdvcil_amd import functional as Fn
+    K_ = 9
+    _, mod, _ = _pair(50, 'SimpleLinear', 'CrossEntropyLoss', K=K_, dev=dev, seed=2)
+    imgs, labels = _clips(2, 8, 64, K_, seed=8)
+    mod.train()
+
+    def run():
+        mod.zero_grad(set_to_none=True)
+        loss = mod(imgs.to(dev), labels.to(dev))['loss_cls']
+        loss.backward()
+        return loss.item(), {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
+
+    assert Fn.FUSE_STAGE
+    l1, g1 = run()
+    calls = []
+    h = mod.backbone.layer2[1].register_forward_hook(lambda m, i, o: calls.append(tuple(o.shape)))
+    l2, g2 = run()                       # layer2 now runs block by block (the hook must see the block output)
+    h.remove()
+    assert len(calls) == 1 and calls[0][1] == 512
+    Fn.FUSE_STAGE = False
+    try:
+        l3, g3 = run()
+    finally:
+        Fn.FUSE_STAGE = True
+    assert abs(l1 - l3) <= 1e-6 * max(1.0, abs(l3)) and abs(l2 - l3) <= 1e-6 * max(1.0, abs(l3))
+    for n in g3:
+        assert _rel_l2(g1[n], g3[n]) <= 2e-4, n
+        assert _rel_l2(g2[n], g3[n]) <= 2e-4, n
