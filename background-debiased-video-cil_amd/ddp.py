@@ -14,15 +14,19 @@ SyncBN in the reference).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
 import torch.distributed as dist
 
+# BDVCIL_FORCE_DIST=1: issue the collectives even in a one-rank process group (exercises the RCCL path on one GPU)
+_FORCE = os.environ.get('BDVCIL_FORCE_DIST', '0') != '0'
+
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0):
     """One-time parameter/buffer broadcast at construction (what DDP does in its constructor)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _FORCE):
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
@@ -118,7 +122,7 @@ class GradAllReducer:
             if on_gpu:
                 for g in grads:
                     g.record_stream(self._comm_stream)
-            if self.world > 1:
+            if self.world > 1 or (_FORCE and dist.is_initialized()):
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if on_gpu:
                 b.event = torch.cuda.Event()

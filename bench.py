@@ -169,8 +169,12 @@ def main():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # BDVCIL_FORCE_DIST=1 exercises the RCCL path (process group, bucketed all-reduce, barrier) on a single rank
+    force_dist = world == 1 and os.environ.get('BDVCIL_FORCE_DIST', '0') != '0'
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     import bdvcil_amd as bd
@@ -188,7 +192,7 @@ def main():
     model = bd.build_model(model_cfg(args.depth, args.classes, args.head, args.loss, args.dropout)).to(dev)
     model.train()
     reducer = None
-    if world > 1:
+    if use_dist:
         bd.broadcast_parameters(model)
         reducer = bd.GradAllReducer(model, bucket_cap_mb=25.0)
     opt = bd.build_optimizer(model, dict(type='SGD', constructor='CILTSMOptimizerConstructorImprovised',
@@ -233,7 +237,7 @@ def main():
         batch = dict(imgs=imgs, label=labels)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -249,7 +253,7 @@ def main():
     dt = time.perf_counter() - t0
     timer.enabled = False
     loss_val = float(out['loss_cls'].item())
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -299,7 +303,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not cil and not predict:
             res['cpu_baseline'] = cpu_baseline(args.depth, args.classes, args.head, args.loss)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
