@@ -87,7 +87,9 @@ __device__ __forceinline__ void store_transposed(float* __restrict__ dst, const 
 }
 
 template <int BM, int BN, int WM, int WN, int MINB, bool PAIR = false>
-__global__ __launch_bounds__(256, MINB) void kg(const float* __restrict__ A, const float* __restrict__ B, float* out, int iters, int ld) {
+__global__ __launch_bounds__(256, MINB) void kg(const float* __restrict__ A, const float* __restrict__ B, float* out, int iters, int ld, int stagger = 0) {
+  // desynchronise the blocks that share a CU: block b, b + 256, b + 512 start 0, 1, 2 x `stagger` x 64 cycles apart
+  for (int z = 0; z < (int)((blockIdx.x / 256) % 3) * stagger; ++z) __builtin_amdgcn_s_sleep(1);
   constexpr int AP = BM / 32, BP = BN / 32;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   __shared__ __attribute__((aligned(16))) float smem[BK * (BM + BN)];
@@ -139,9 +141,9 @@ void run(const char* name, int K, float* A, float* B, float* d, int ld) {
   for (int mult : {1, 2, 3, 4, 6, 12}) {
     const int blocks = 256 * mult;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, A, B, d, iters, ld); hipDeviceSynchronize();
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, A, B, d, iters, ld, 0); hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, A, B, d, iters, ld);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, A, B, d, iters, ld, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
     double flops = (double)blocks * K * BM * BN * 2.0;
@@ -149,14 +151,49 @@ void run(const char* name, int K, float* A, float* B, float* d, int ld) {
   }
 }
 
+template <int BM, int BN, int WM, int WN, int MINB>
+void ksweep(const char* name, float* A, float* B, float* d, int ld) {
+  auto kern = kg<BM, BN, WM, WN, MINB, false>;
+  for (int K : {576, 1152, 2304, 4608, 9216}) {
+    const int iters = K / BK, blocks = 768;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, A, B, d, iters, ld, 0); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, A, B, d, iters, ld, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    double flops = (double)blocks * K * BM * BN * 2.0;
+    printf("%-30s K %5d (768 blocks): %.3f ms  %.1f TFLOP/s\n", name, K, ms, flops / ms / 1e9);
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int MINB>
+void stagger_sweep(const char* name, float* A, float* B, float* d, int ld) {
+  auto kern = kg<BM, BN, WM, WN, MINB, false>;
+  const int K = 2304, iters = K / BK;
+  for (int blocks : {768, 1536})
+    for (int st : {0, 20, 40, 73, 110, 150, 220}) {
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, A, B, d, iters, ld, st); hipDeviceSynchronize();
+      hipEventRecord(e0);
+      for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, A, B, d, iters, ld, st);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+      double flops = (double)blocks * K * BM * BN * 2.0;
+      printf("%-24s blocks %4d stagger %3d: %.3f ms  %.1f TFLOP/s\n", name, blocks, st, ms, flops / ms / 1e9);
+    }
+}
+
 int main() {
-  const int K = 2304, ld = K + 64;
+  const int K = 2304, ld = 9216 + 64;
   float *A, *B, *d;
   size_t na = (size_t)128 * 256 * ld + 4096, nb = (size_t)4 * 256 * ld + 4096;
   hipMalloc(&A, na * 4); hipMalloc(&B, nb * 4); hipMalloc(&d, (size_t)4096 * 512 * 4);
   float* h = (float*)malloc(na * 4);
   for (size_t i = 0; i < na; ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
   hipMemcpy(A, h, na * 4, hipMemcpyHostToDevice); hipMemcpy(B, h, nb * 4, hipMemcpyHostToDevice);
+  ksweep<128, 128, 2, 2, 3>("128x128 K sweep", A, B, d, ld);
+  stagger_sweep<128, 128, 2, 2, 3>("128x128 stagger", A, B, d, ld);
   run<128, 128, 2, 2, 3>("128x128 wave 64x64, 3 blocks/CU", K, A, B, d, ld);
   run<128, 128, 2, 2, 3, true>("128x128 row-pair b64 reads", K, A, B, d, ld);
   run<256, 128, 2, 2, 2>("256x128 wave 128x64, 2 blocks/CU", K, A, B, d, ld);
