@@ -308,3 +308,26 @@ def test_fprop_folded_eval_batchnorm(case, res, relu, dev):
     _close(out, ref, tol=1e-6)
     with pytest.raises(ValueError):
         K.conv_fprop(xd, wd, g, bn_stats=True, affine=(scale, shift, r, relu))
+
+
+def test_integration_md_ctypes_stub_runs(dev):
+    """The hand-written ctypes binding shown in INTEGRATION.md section 2 is executed verbatim (guards doc drift) and
+    its result is checked against the package's own wrapper."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    m = re.search(r"```python\nimport ctypes, torch\n(.*?)```", text, re.S)
+    assert m, 'ctypes stub not found in INTEGRATION.md'
+    code = 'import ctypes, torch\n' + m.group(1)
+    code = code.replace("'background-debiased-video-cil_amd/csrc/libbdvcil_hip.so'",
+                        repr(os.path.join(root, 'background-debiased-video-cil_amd', 'csrc', 'libbdvcil_hip.so')))
+    code = code.replace('torch.randn(256, 56, 56, 256', 'torch.randn(16, 56, 56, 256').replace(
+        'ConvGeom(256, 56, 56, 256', 'ConvGeom(16, 56, 56, 256').replace('torch.empty(256, 56, 56, 128', 'torch.empty(16, 56, 56, 128')
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    torch.cuda.synchronize()
+    from bdvcil_amd import kernels as K
+    g = K.make_geom(16, 56, 56, 256, 128, 1, 1, 1, 0, 8, 32)
+    ref = K.conv_fprop(ns['x'], ns['w'], g)
+    assert torch.equal(ns['y'], ref)
