@@ -390,6 +390,21 @@ __global__ __launch_bounds__(256) void icarl_targets_kernel(const int64_t* __res
   }
 }
 
+// ActorCutMix smooth labels (libs/losses/acm_smooth_ce.py:18-28): y = onehot(label) * lam + (1 - lam) * onehot(bg),
+// lam = 1 - (1 - foreground_ratio)^alpha, background label -1 counted as class 0.  One wave per row.
+__global__ __launch_bounds__(256) void acm_targets_kernel(const int64_t* __restrict__ labels, const int64_t* __restrict__ bg,
+                                                           const float* __restrict__ fg_ratio, float alpha,
+                                                           float* __restrict__ tgt, int B, int K) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int y = (int)labels[b];
+  int yb = (int)bg[b];
+  if (yb == -1) yb = 0;
+  const float lam = 1.f - powf(1.f - fg_ratio[b], alpha);
+  for (int k = lane; k < K; k += 64) tgt[(size_t)b * K + k] = (k == y ? 1.f : 0.f) * lam + (1.f - lam) * (k == yb ? 1.f : 0.f);
+}
+
 // average_clip: out[b,:] = mean_i softmax(s[b*n+i,:])  (or plain mean); one wave per b
 __global__ __launch_bounds__(256) void softmax_mean_kernel(const float* __restrict__ s, float* __restrict__ out, int B, int n, int K,
                                                             int apply_softmax) {
@@ -584,6 +599,15 @@ extern "C" int bdv_icarl_targets(const int64_t* labels, const float* prev_logits
   BDV_REQUIRE(labels && targets && B > 0 && K > 0, "bdv_icarl_targets: bad argument");
   hipLaunchKernelGGL(icarl_targets_kernel, dim3((B + 3) / 4), dim3(256), 0, HL_STREAM, labels, prev_logits, prev_K, targets, B, K);
   BDV_LAUNCH_CHECK("bdv_icarl_targets");
+  return BDV_OK;
+}
+
+extern "C" int bdv_acm_targets(const int64_t* labels, const int64_t* background_labels, const float* foreground_ratio, float alpha,
+                               float* targets, int B, int K, void* stream) {
+  BDV_REQUIRE(labels && background_labels && foreground_ratio && targets && B > 0 && K > 0, "bdv_acm_targets: bad argument");
+  hipLaunchKernelGGL(acm_targets_kernel, dim3((B + 3) / 4), dim3(256), 0, HL_STREAM, labels, background_labels, foreground_ratio,
+                     alpha, targets, B, K);
+  BDV_LAUNCH_CHECK("bdv_acm_targets");
   return BDV_OK;
 }
 

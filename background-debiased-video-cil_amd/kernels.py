@@ -496,6 +496,19 @@ def icarl_targets(labels, prev_logits, prev_K, K):
     return tgt
 
 
+def acm_targets(labels, background_labels, foreground_ratio, alpha, K):
+    """ACMSmoothCE smooth labels (libs/losses/acm_smooth_ce.py:18-28) -> (B, K)."""
+    B = labels.numel()
+    labels = labels.reshape(B)
+    _chk(labels, (B,), dtype=torch.int64, name='labels')
+    _chk(background_labels, (B,), dtype=torch.int64, name='background_labels')
+    _chk(foreground_ratio, (B,), name='foreground_ratio')
+    tgt = torch.empty((B, K), dtype=torch.float32, device=labels.device)
+    check(lib().bdv_acm_targets(_p(labels), _p(background_labels), _p(foreground_ratio), float(alpha), _p(tgt), B, K, _stream()),
+          'bdv_acm_targets')
+    return tgt
+
+
 def softmax_mean(s, B, n, apply_softmax=True):
     _chk(s, name='s')
     K = s.shape[1]

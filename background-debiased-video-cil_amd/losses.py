@@ -66,13 +66,19 @@ class SoftTargetCrossEntropy(nn.Module):
 
 @LOSSES.register_module()
 class ACMSmoothCE(nn.Module):
-    """API name kept for config compatibility (libs/losses/acm_smooth_ce.py:8-30).  Unreachable in every
-    shipped config (all ACM configs use methods='icarl', which bypasses head.loss -- SURVEY section 2 #8),
-    so it is out of scope for the HIP path."""
+    """ActorCutMix smooth-label loss (libs/losses/acm_smooth_ce.py:8-30): labels are mixed with the background label by
+    ``lambda = 1 - (1 - foreground_ratio)^alpha`` and the loss is ``mean_b(sum_k y * log_softmax(score))`` -- with the
+    reference's sign (no negation).  No shipped config reaches it (all ACM configs train with methods='icarl', which
+    bypasses ``head.loss``); it is provided so that the ``libs.losses`` plugin surface is complete.  Like the reference,
+    ``batch_data['background_label']`` is modified in place (-1 -> 0)."""
 
     def __init__(self, alpha: float = 4):
         super().__init__()
         self.alpha = alpha
 
     def forward(self, cls_score, labels, batch_data, num_classes, **kwargs):
-        raise NotImplementedError('ACMSmoothCE is out of the hot-path scope (never invoked by the reference configs)')
+        background_labels = torch.squeeze(batch_data['background_label'], dim=1)
+        background_labels[background_labels == -1] = 0
+        fg = batch_data['foreground_ratio'].reshape(-1).to(torch.float32).contiguous()
+        tgt = K.acm_targets(labels.reshape(-1).contiguous(), background_labels.contiguous(), fg, self.alpha, int(num_classes))
+        return -Fn.SoftCEFn.apply(cls_score, tgt, None)

@@ -203,6 +203,10 @@ int bdv_softce_loss(const float* score, const float* soft_targets, const int64_t
 /* icarl.py:101,113-120: targets = onehot(label); rows with label < prev_K <- softmax(prev_logits) */
 int bdv_icarl_targets(const int64_t* labels, const float* prev_logits, int prev_K, float* targets,
                       int B, int K, void* stream);
+/* libs/losses/acm_smooth_ce.py:18-28 (ACMSmoothCE smooth labels): targets = onehot(label) * lam + (1 - lam) *
+ * onehot(background_label), lam = 1 - (1 - foreground_ratio)^alpha; background label -1 counts as class 0. */
+int bdv_acm_targets(const int64_t* labels, const int64_t* background_labels, const float* foreground_ratio, float alpha,
+                    float* targets, int B, int K, void* stream);
 /* UPSTREAM Recognizer2D average_clip('prob'): (B*n,K) -> softmax over K, mean over n -> (B,K) */
 int bdv_softmax_mean(const float* s, float* out, int B, int n, int K, int apply_softmax, void* stream);
 /* UPSTREAM top_k_accuracy: acc[0]=top-1, acc[1]=top-5 hit rates, computed on device (no D2H sync) */

@@ -286,6 +286,18 @@ def icarl_targets(labels: torch.Tensor, num_classes: int, prev_logits: Optional[
     return tgt
 
 
+def acm_smooth_ce(cls_score: torch.Tensor, labels: torch.Tensor, background_label: torch.Tensor,
+                  foreground_ratio: torch.Tensor, num_classes: int, alpha: float = 4.0) -> torch.Tensor:
+    """libs/losses/acm_smooth_ce.py:13-30 (sign as in the reference: no negation; background label -1 -> 0)."""
+    action = F.one_hot(labels, num_classes=num_classes)
+    bg = torch.squeeze(background_label, dim=1).clone()
+    bg[bg == -1] = 0
+    bg = F.one_hot(bg, num_classes=num_classes)
+    lam = 1 - (1 - foreground_ratio) ** alpha
+    y = action * lam + (1 - lam) * bg
+    return torch.mean(torch.sum(y * F.log_softmax(cls_score, dim=1), dim=1), dim=0)
+
+
 def top_k_hits(scores: torch.Tensor, labels: torch.Tensor, k: int) -> float:
     """UPSTREAM mmaction top_k_accuracy (hit iff the label is among the k best scores)."""
     lab = scores.gather(1, labels.view(-1, 1))

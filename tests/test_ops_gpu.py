@@ -273,3 +273,22 @@ def test_multi_tensor_sgd_and_clip(dev):
         torch.cuda.synchronize()
         for a, b in zip(dp, ref_p):
             _close(a, b, tol=1e-5, atol=1e-7)
+
+
+def test_acm_smooth_ce_matches_reference_golden(dev):
+    """libs.losses.ACMSmoothCE on the HIP path vs golden vectors from the reference's own acm_smooth_ce.py."""
+    import os
+    import bdvcil_amd as bd
+    gz = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'acm_golden.npz'))
+    for i in range(int(gz['n'])):
+        p = f'c{i}_'
+        score = torch.from_numpy(gz[p + 'score']).to(dev).requires_grad_(True)
+        K = score.shape[1]
+        bg = torch.from_numpy(gz[p + 'bg']).to(dev)
+        crit = bd.build_loss(dict(type='ACMSmoothCE', alpha=float(gz[p + 'alpha'])))
+        loss = crit(score, torch.from_numpy(gz[p + 'labels']).to(dev),
+                    {'background_label': bg, 'foreground_ratio': torch.from_numpy(gz[p + 'fg']).to(dev)}, K)
+        loss.backward()
+        assert abs(loss.item() - float(gz[p + 'loss'])) <= 1e-5 * max(1.0, abs(float(gz[p + 'loss'])))
+        assert torch.allclose(score.grad.cpu(), torch.from_numpy(gz[p + 'dscore']), rtol=1e-4, atol=1e-7)
+        assert int((bg == -1).sum()) == 0          # like the reference, the background labels are rewritten in place

@@ -136,3 +136,15 @@ def test_forward_shapes_and_b1_squeeze():
     with torch.no_grad():
         p = m(imgs, return_loss=False)
     assert p.shape == (1, 5) and abs(p.sum().item() - 1.0) < 1e-5          # average_clips='prob'
+
+
+def test_acm_smooth_ce_matches_reference_golden():
+    gz = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'acm_golden.npz'))
+    for i in range(int(gz['n'])):
+        p = f'c{i}_'
+        score = _t(gz[p + 'score']).requires_grad_(True)
+        K = score.shape[1]
+        loss = O.acm_smooth_ce(score, _t(gz[p + 'labels']), _t(gz[p + 'bg']), _t(gz[p + 'fg']), K, float(gz[p + 'alpha']))
+        loss.backward()
+        assert torch.allclose(loss, _t(gz[p + 'loss']), rtol=1e-6, atol=1e-7)
+        assert torch.allclose(score.grad, _t(gz[p + 'dscore']), rtol=1e-5, atol=1e-8)
