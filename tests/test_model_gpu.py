@@ -273,3 +273,26 @@ def test_stage_node_matches_block_nodes(dev):
     for n in g3:
         assert _rel_l2(g1[n], g3[n]) <= 2e-4, n
         assert _rel_l2(g2[n], g3[n]) <= 2e-4, n
+
+
+def test_training_step_is_run_to_run_deterministic(dev):
+    """No atomics anywhere on the path (split-K slabs, BN partial sums and loss reductions are summed in fixed order):
+    two runs of the same step from the same state give bit-identical loss and gradients."""
+    _, mod, _ = _pair(50, 'LocalSimilarityClassifier', 'LSCLoss', K=9, dev=dev, seed=4)
+    imgs, labels = _clips(2, 8, 96, 9, seed=6)
+    mod.train()
+    x, y = imgs.to(dev), labels.to(dev)
+    state = {k: v.clone() for k, v in mod.state_dict().items()}
+
+    def run():
+        mod.load_state_dict(state)
+        mod.zero_grad(set_to_none=True)
+        loss = mod(x, y)['loss_cls']
+        loss.backward()
+        return loss.detach().clone(), {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
+
+    l1, g1 = run()
+    l2, g2 = run()
+    assert torch.equal(l1, l2)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
