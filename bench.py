@@ -276,7 +276,7 @@ def main():
                        'final_loss': round(loss_val, 5)},
         }
         if flop_per_clip:
-            res['config']['model_flop_per_clip'] = flop_per_clip
+            res['config']['algorithmic_flop_per_clip'] = flop_per_clip
             res['config']['step_frac_of_f32_mfma_peak'] = round(value / world * flop_per_clip / PEAK_F32_MFMA, 4)
         if not args.no_kernel_timing and timer.records:
             by = timer.summary()
