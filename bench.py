@@ -270,7 +270,7 @@ def main():
             'ms_per_step': round(1000.0 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': ('CIL task-1 step (uint8 bg-mix front-end, frozen teacher forward, 5 feature-KD MSE terms, clip 1.0): ' if cil else '')
-                                   + f'TSM-ResNet{args.depth} fwd+bwd+SGD step, synthetic {args.batch}x8x3x224x224 clips per GPU, '
+                                   + f'TSM-ResNet{args.depth} ' + ('eval forward + clip representations (predict_step)' if predict else 'fwd+bwd+SGD step') + f', synthetic {args.batch}x8x3x224x224 clips per GPU, '
                                    f'{args.classes} classes, {args.head}+{args.loss}, dropout {args.dropout}, random-init weights',
                        'clips_per_gpu': args.batch, 'global_batch': args.batch * world, 'parallelism': f'dp{world}',
                        'final_loss': round(loss_val, 5)},
