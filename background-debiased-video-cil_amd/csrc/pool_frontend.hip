@@ -50,6 +50,64 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float4* __restri
   }
 }
 
+// Stem tail in one pass: a = relu(y * scale + shift) (train-mode BatchNorm apply), MaxPool2d(3, 2, 1) of a, and the
+// 1-bit ReLU mask of a -- the activation itself is never written (it is only needed pooled, and as a sign mask by the
+// BatchNorm backward).  thread = (pooled pixel, 4 channels); the thread also owns the 2x2 input pixels
+// (2ho..2ho+1, 2wo..2wo+1), which lie inside its window, for the mask: 8 neighbouring lanes hold the 32 channels of one
+// pixel and merge their nibbles into the mask word.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
+                                                                   const float4* __restrict__ shift, float4* __restrict__ out,
+                                                                   uchar4* __restrict__ idx, uint32_t* __restrict__ mask, int N,
+                                                                   int H, int W, int CV, int Ho, int Wo) {
+  for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
+    const int n = row / Ho, ho = row - n * Ho;
+    const float4* yin = y + (int64_t)n * H * W * CV;
+    const int64_t orow = ((int64_t)n * Ho + ho) * Wo * CV;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Wo * CV; i += gridDim.x * blockDim.x) {
+      const int wo = i / CV, c4 = i - wo * CV;
+      const float4 sc = scale[c4], sh = shift[c4];
+      float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      uchar4 mi = make_uchar4(255, 255, 255, 255);
+      unsigned nib[2][2] = {{0u, 0u}, {0u, 0u}};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int hi = 2 * ho - 1 + r;
+        if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int wi = 2 * wo - 1 + s;
+          if ((unsigned)wi >= (unsigned)W) continue;
+          float4 v = yin[(hi * W + wi) * CV + c4];
+          v.x = fmaxf(v.x * sc.x + sh.x, 0.f);
+          v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+          v.z = fmaxf(v.z * sc.z + sh.z, 0.f);
+          v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+          const unsigned char t = (unsigned char)(r * 3 + s);
+          if (v.x > m.x || mi.x == 255) { m.x = v.x; mi.x = t; }
+          if (v.y > m.y || mi.y == 255) { m.y = v.y; mi.y = t; }
+          if (v.z > m.z || mi.z == 255) { m.z = v.z; mi.z = t; }
+          if (v.w > m.w || mi.w == 255) { m.w = v.w; mi.w = t; }
+          if (r >= 1 && s >= 1)
+            nib[r - 1][s - 1] = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+        }
+      }
+      out[orow + i] = m;
+      idx[orow + i] = mi;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          unsigned w32 = nib[a][b] << (4 * (c4 & 7));
+          w32 |= __shfl_xor(w32, 1, 64);
+          w32 |= __shfl_xor(w32, 2, 64);
+          w32 |= __shfl_xor(w32, 4, 64);
+          const int hi = 2 * ho + a, wi = 2 * wo + b;
+          if ((c4 & 7) == 0 && hi < H && wi < W) mask[(((int64_t)n * H + hi) * W + wi) * (CV / 8) + (c4 >> 3)] = w32;
+        }
+    }
+  }
+}
+
 // Backward as a gather without divergence: a thread owns the 2x2 input block (2i..2i+1, 2j..2j+1) x 4 channels.  Those
 // four pixels are covered by exactly the windows (i,j), (i,j+1), (i+1,j), (i+1,j+1), each loaded once; a pixel takes a
 // window's gradient when the stored arg-max code equals its position (r*3+s) inside that window.  Contributions are
@@ -211,6 +269,22 @@ extern "C" int bdv_maxpool_fwd(const float* x, float* out, uint8_t* idx, int N, 
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((rowv + 255) / 256, N * Ho < 65535 ? N * Ho : 65535), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
                      (float4*)out, (uchar4*)idx, N, H, W, C / 4, Ho, Wo);
   BDV_LAUNCH_CHECK("bdv_maxpool_fwd");
+  return BDV_OK;
+}
+
+extern "C" int bdv_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, uint8_t* idx,
+                                       uint32_t* relu_mask, int N, int H, int W, int C, void* stream) {
+  BDV_REQUIRE(y && scale && shift && out && idx && relu_mask && N > 0 && H > 1 && W > 1 && C > 0 && C % 32 == 0,
+              "bdv_bn_relu_maxpool_fwd: bad argument (C must be a multiple of 32)");
+  BDV_REQUIRE(bdv_aligned16(y) && bdv_aligned16(scale) && bdv_aligned16(shift) && bdv_aligned16(out) &&
+                  (((uintptr_t)idx) & 3) == 0 && (((uintptr_t)relu_mask) & 3) == 0, "bdv_bn_relu_maxpool_fwd: alignment");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  BDV_REQUIRE((int64_t)H * W * (C / 4) < (1ll << 31) && (int64_t)N * Ho < (1ll << 31), "bdv_bn_relu_maxpool_fwd: too large");
+  const int rowv = Wo * (C / 4);
+  hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3((rowv + 255) / 256, N * Ho < 65535 ? N * Ho : 65535), dim3(256), 0,
+                     (hipStream_t)stream, (const float4*)y, (const float4*)scale, (const float4*)shift, (float4*)out, (uchar4*)idx,
+                     relu_mask, N, H, W, C / 4, Ho, Wo);
+  BDV_LAUNCH_CHECK("bdv_bn_relu_maxpool_fwd");
   return BDV_OK;
 }
 

@@ -159,18 +159,19 @@ class StemFn(torch.autograd.Function):
         w4 = torch.zeros((weight.shape[0], weight.shape[2], weight.shape[3], 4), dtype=torch.float32, device=x4.device)
         w4[..., :3] = weight.detach().permute(0, 2, 3, 1)           # 37 KB repack, plumbing
         save = training and any(ctx.needs_input_grad)
-        if not training:
-            a, mask, y, mean, invstd = _conv_bn_eval(x4, w4, g, bn, gamma, beta, None, True), None, None, None, None
-        else:
+        if training:
             y, mean, invstd, scale, shift = _conv_bn_forward(x4, w4, g, bn, gamma, beta, training)
-            if save:
-                a, mask = K.bn_apply(y, scale, shift, None, True, want_mask=True)
-            else:
-                a, mask = K.bn_apply(y, scale, shift, None, True, out=y), None
-        p, idx = K.maxpool_fwd(a)
+            # BN apply + ReLU + max-pool + ReLU sign mask in one pass; the activation itself is never materialised
+            p, idx, mask = K.bn_relu_maxpool_fwd(y, scale, shift)
+            a_shape = tuple(y.shape)
+        else:
+            a = _conv_bn_eval(x4, w4, g, bn, gamma, beta, None, True)
+            p, idx = K.maxpool_fwd(a)
+            a_shape = tuple(a.shape)
+            y = mask = mean = invstd = None
         ctx.g = g
         ctx.bn_training = training
-        ctx.a_shape = tuple(a.shape)
+        ctx.a_shape = a_shape
         if save:
             ctx.save_for_backward(x4, gamma, y, mask, idx, mean, invstd)
         return p

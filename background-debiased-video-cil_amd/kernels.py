@@ -317,6 +317,21 @@ def maxpool_fwd(x):
     return out, idx
 
 
+def bn_relu_maxpool_fwd(y, scale, shift):
+    """Stem tail: relu(y * scale + shift) -> MaxPool2d(3,2,1) in one pass -> (pooled, idx, relu_mask of the activation)."""
+    _chk(y, name='y')
+    N, H, W, C = y.shape
+    _chk(scale, (C,), name='scale')
+    _chk(shift, (C,), name='shift')
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=y.device)
+    idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=y.device)
+    mask = torch.empty(y.numel() // 32, dtype=torch.int32, device=y.device)
+    check(lib().bdv_bn_relu_maxpool_fwd(_p(y), _p(scale), _p(shift), _p(out), _p(idx), _p(mask), N, H, W, C, _stream()),
+          'bdv_bn_relu_maxpool_fwd')
+    return out, idx, mask
+
+
 def maxpool_bwd(dout, idx, in_shape):
     N, H, W, C = in_shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1

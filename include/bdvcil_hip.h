@@ -158,6 +158,11 @@ int bdv_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* st
  * per output element (first maximum in scan order, as torch). */
 int bdv_maxpool_fwd(const float* x, float* out, uint8_t* idx, int N, int H, int W, int C, void* stream);
 int bdv_maxpool_bwd(const float* dout, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream);
+/* Stem tail of a training forward in one pass (UPSTREAM ConvModule norm+act, then ResNet.maxpool): a = relu(y * scale +
+ * shift), out = maxpool(a), idx as bdv_maxpool_fwd, relu_mask = 1 bit per element of a (a > 0) as bdv_bn_apply writes it.
+ * The activation a itself is not materialised. */
+int bdv_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, uint8_t* idx,
+                            uint32_t* relu_mask, int N, int H, int W, int C, void* stream);
 /* UPSTREAM TSMHead.avg_pool = AdaptiveAvgPool2d(1): [N,HW,C] -> [N,C] */
 int bdv_avgpool_fwd(const float* x, float* out, int N, int HW, int C, void* stream);
 int bdv_avgpool_bwd(const float* dout, float* dx, int N, int HW, int C, void* stream);

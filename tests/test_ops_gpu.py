@@ -292,3 +292,21 @@ def test_acm_smooth_ce_matches_reference_golden(dev):
         assert abs(loss.item() - float(gz[p + 'loss'])) <= 1e-5 * max(1.0, abs(float(gz[p + 'loss'])))
         assert torch.allclose(score.grad.cpu(), torch.from_numpy(gz[p + 'dscore']), rtol=1e-4, atol=1e-7)
         assert int((bg == -1).sum()) == 0          # like the reference, the background labels are rewritten in place
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64), (3, 15, 11, 64), (2, 112, 112, 64), (1, 9, 14, 128)])
+def test_bn_relu_maxpool_fused_equals_separate_kernels(shape, dev):
+    """Stem tail in one pass == bn_apply (+ReLU, mask) followed by maxpool_fwd, bit for bit (values, arg-max codes, mask)."""
+    from bdvcil_amd import kernels as K
+    g = torch.Generator().manual_seed(17)
+    y = torch.randn(*shape, generator=g).to(dev)
+    C = shape[-1]
+    scale = (torch.rand(C, generator=g) + 0.5).to(dev)
+    shift = (torch.randn(C, generator=g) * 0.5).to(dev)
+    a, mask_ref = K.bn_apply(y, scale, shift, None, True, want_mask=True)
+    out_ref, idx_ref = K.maxpool_fwd(a)
+    out, idx, mask = K.bn_relu_maxpool_fwd(y, scale, shift)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_ref)
+    assert torch.equal(idx, idx_ref)
+    assert torch.equal(mask, mask_ref)

@@ -25,3 +25,10 @@ for (H, C) in [(112, 64), (56, 64), (56, 256), (28, 512), (14, 1024), (7, 2048)]
     part = torch.randn(2, (M + 127) // 128, C, device=dev)
     gamma = torch.ones(C, device=dev); beta = torch.zeros(C, device=dev)
     print('bn_train_finalize M/128=%5d C=%4d: %.1f us' % (part.shape[1], C, timeit(lambda: K.bn_train_finalize(part, M, gamma, beta, 1e-5, 0.1, None, None))))
+yy = torch.randn(256, 112, 112, 64, device=dev)
+sc = torch.rand(64, device=dev) + 0.5; sh = torch.randn(64, device=dev)
+def separate():
+    a_, m_ = K.bn_apply(yy, sc, sh, None, True, want_mask=True)
+    return K.maxpool_fwd(a_)
+print('stem tail separate (bn_apply + maxpool_fwd) %.1f us' % timeit(separate))
+print('stem tail fused    (bn_relu_maxpool_fwd)    %.1f us' % timeit(lambda: K.bn_relu_maxpool_fwd(yy, sc, sh)))
