@@ -284,6 +284,78 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
   }
 }
 
+// ---- BatchNorm(+ReLU) backward behind a MaxPool2d(3, 2, 1) (the stem) --------------------------------------------
+// The gradient entering the BN+ReLU is the max-pool backward of dpool; it is gathered on the fly (pool_bwd_gather2x2)
+// in both passes instead of being materialised: thread = (2x2 input block, 4 channels), grid.y strides (frame, block
+// row).  256 % CV == 0, so a thread keeps its 4 channels and the per-block reduction groups threads by tid % CV.
+template <bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_pool_kernel(const float4* __restrict__ dpool, const uchar4* __restrict__ idx,
+                                                           const uint32_t* __restrict__ mask, const float4* __restrict__ y,
+                                                           const float4* __restrict__ mean, const float4* __restrict__ invstd,
+                                                           const float4* __restrict__ coef, float4* __restrict__ dy,
+                                                           float* __restrict__ p1, float* __restrict__ p2, int N, int H, int W,
+                                                           int CV, int Ho, int Wo) {
+  __shared__ float4 sh[2][256];
+  const int tid = threadIdx.x;
+  const int c4 = tid % CV;
+  const float4 mu = mean[c4], is = invstd[c4];
+  float4 ca, cb, cc;
+  if (APPLY) {
+    ca = coef[c4];
+    cb = coef[CV + c4];
+    cc = coef[2 * CV + c4];
+  }
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
+    const int n = row / Ho, i = row - n * Ho;
+    const int64_t obase = (int64_t)n * Ho * Wo * CV;
+    const int64_t ibase = (int64_t)n * H * W * CV;
+    const bool down = i + 1 < Ho, h1ok = 2 * i + 1 < H;
+    for (int q = blockIdx.x * blockDim.x + tid; q < Wo * CV; q += gridDim.x * blockDim.x) {
+      const int j = q / CV;  // q % CV == c4
+      const bool right = j + 1 < Wo, w1ok = 2 * j + 1 < W;
+      float4 g[4];
+      pool_bwd_gather2x2(dpool, idx, obase + (i * Wo + j) * CV + c4, CV, Wo, right, down, g);
+      const int64_t p00 = ibase + ((2 * i) * W + 2 * j) * CV + c4;
+      const int64_t pix[4] = {p00, p00 + CV, p00 + (int64_t)W * CV, p00 + (int64_t)(W + 1) * CV};
+      const bool ok[4] = {true, w1ok, h1ok, h1ok && w1ok};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!ok[k]) continue;
+        const float4 gv = apply_nibble(g[k], mask_nibble(mask, pix[k]));
+        const float4 v = y[pix[k]];
+        const float4 xh = make_float4((v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w);
+        if (APPLY) {
+          float4 d;
+          d.x = ca.x * (gv.x - cb.x - xh.x * cc.x);
+          d.y = ca.y * (gv.y - cb.y - xh.y * cc.y);
+          d.z = ca.z * (gv.z - cb.z - xh.z * cc.z);
+          d.w = ca.w * (gv.w - cb.w - xh.w * cc.w);
+          dy[pix[k]] = d;
+        } else {
+          s1.x += gv.x; s1.y += gv.y; s1.z += gv.z; s1.w += gv.w;
+          s2.x += gv.x * xh.x; s2.y += gv.y * xh.y; s2.z += gv.z * xh.z; s2.w += gv.w * xh.w;
+        }
+      }
+    }
+  }
+  if (!APPLY) {
+    sh[0][tid] = s1;
+    sh[1][tid] = s2;
+    __syncthreads();
+    if (tid < CV) {
+      for (int k = 1; k < 256 / CV; ++k) {
+        const float4 a = sh[0][k * CV + tid], b = sh[1][k * CV + tid];
+        s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+        s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+      }
+      const int64_t slab_row = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+      reinterpret_cast<float4*>(p1)[slab_row * CV + tid] = s1;
+      reinterpret_cast<float4*>(p2)[slab_row * CV + tid] = s2;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float4* __restrict__ dout, const uint32_t* __restrict__ mask,
                                                         const float4* __restrict__ add, float4* __restrict__ g, int64_t n4) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -436,6 +508,49 @@ extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, con
     hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, blk, 0, s, (const float4*)dout, relu_mask, (const float4*)y,
                        (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy, n4, C / 4);
   BDV_LAUNCH_CHECK("bdv_bn_backward(apply)");
+  return BDV_OK;
+}
+
+extern "C" int bdv_bn_backward_maxpool(const float* dpool, const uint8_t* pool_idx, const uint32_t* relu_mask, const float* y,
+                                       const float* gamma, const float* save_mean, const float* save_invstd, float* dy,
+                                       float* dgamma, float* dbeta, float beta_acc, int N, int H, int W, int C, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  BDV_REQUIRE(dpool && pool_idx && relu_mask && y && gamma && save_mean && save_invstd && dy && workspace,
+              "bdv_bn_backward_maxpool: null pointer");
+  BDV_REQUIRE(N > 0 && H > 1 && W > 1 && C >= 32 && C % 32 == 0 && 256 % (C / 4) == 0,
+              "bdv_bn_backward_maxpool: unsupported shape (C must be 32, 64, 128, 256, 512 or 1024)");
+  BDV_REQUIRE(bdv_aligned16(dpool) && bdv_aligned16(y) && bdv_aligned16(dy) && bdv_aligned16(workspace) &&
+                  bdv_aligned16(save_mean) && bdv_aligned16(save_invstd) && (((uintptr_t)pool_idx) & 3) == 0,
+              "bdv_bn_backward_maxpool: alignment");
+  const int64_t M = (int64_t)N * H * W;
+  BDV_REQUIRE(M * (C / 4) < (1ll << 31), "bdv_bn_backward_maxpool: tensor too large");
+  if (workspace_bytes < bdv_bn_workspace_bytes(M, C)) {
+    bdv_set_error("bdv_bn_backward_maxpool: workspace too small");
+    return BDV_EWORKSPACE;
+  }
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, CV = C / 4;
+  const int gx = (Wo * CV + 255) / 256;
+  int gy = N * Ho;
+  const int cap = MAX_RB_TIMES_C / C / gx;  // slab rows = gx * gy
+  if (gy > cap) gy = cap;
+  if (gy > 4096) gy = 4096;
+  BDV_REQUIRE(gy >= 1, "bdv_bn_backward_maxpool: row too wide for the partial slab");
+  float* p1 = (float*)workspace;
+  float* p2 = p1 + MAX_RB_TIMES_C;
+  float* coef = p2 + MAX_RB_TIMES_C;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(gx, gy), blk(256);
+  hipLaunchKernelGGL((bn_bwd_pool_kernel<false>), grid, blk, 0, s, (const float4*)dpool, (const uchar4*)pool_idx, relu_mask,
+                     (const float4*)y, (const float4*)save_mean, (const float4*)save_invstd, (const float4*)nullptr,
+                     (float4*)nullptr, p1, p2, N, H, W, CV, Ho, Wo);
+  BDV_LAUNCH_CHECK("bdv_bn_backward_maxpool(partial)");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)p1, (const float*)p2, gx * gy, M, C,
+                     gamma, save_invstd, dgamma, dbeta, beta_acc, coef, save_mean, (float*)nullptr);
+  BDV_LAUNCH_CHECK("bdv_bn_backward_maxpool(finalize)");
+  hipLaunchKernelGGL((bn_bwd_pool_kernel<true>), grid, blk, 0, s, (const float4*)dpool, (const uchar4*)pool_idx, relu_mask,
+                     (const float4*)y, (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy,
+                     (float*)nullptr, (float*)nullptr, N, H, W, CV, Ho, Wo);
+  BDV_LAUNCH_CHECK("bdv_bn_backward_maxpool(apply)");
   return BDV_OK;
 }
 

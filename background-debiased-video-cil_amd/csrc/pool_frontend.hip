@@ -108,21 +108,10 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float4* 
   }
 }
 
-// Backward as a gather without divergence: a thread owns the 2x2 input block (2i..2i+1, 2j..2j+1) x 4 channels.  Those
-// four pixels are covered by exactly the windows (i,j), (i,j+1), (i+1,j), (i+1,j+1), each loaded once; a pixel takes a
-// window's gradient when the stored arg-max code equals its position (r*3+s) inside that window.  Contributions are
-// added in (r, s) scan order, i.e. the same order for every launch shape.  grid.y = (frame, block row i).
-__device__ __forceinline__ void pool_take(float4& g, const uchar4 t, const float4 d, unsigned char me) {
-  if (t.x == me) g.x += d.x;
-  if (t.y == me) g.y += d.y;
-  if (t.z == me) g.z += d.z;
-  if (t.w == me) g.w += d.w;
-}
-
+// Backward as a gather without divergence (pool_bwd_gather2x2 in common.h): a thread owns the 2x2 input block
+// (2i..2i+1, 2j..2j+1) x 4 channels and loads each of the four windows that cover it once.  grid.y = (frame, block row i).
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restrict__ dout, const uchar4* __restrict__ idx,
                                                            float4* __restrict__ dx, int N, int H, int W, int CV, int Ho, int Wo) {
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const uchar4 none = make_uchar4(255, 255, 255, 255);
   for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
     const int n = row / Ho, i = row - n * Ho;
     const int64_t obase = (int64_t)n * Ho * Wo * CV;
@@ -131,38 +120,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restri
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Wo * CV; q += gridDim.x * blockDim.x) {
       const int j = q / CV, c4 = q - j * CV;
       const bool right = j + 1 < Wo, w1ok = 2 * j + 1 < W;
-      const int64_t o00 = obase + (i * Wo + j) * CV + c4;
-      const uchar4 t00 = idx[o00];
-      const float4 d00 = dout[o00];
-      const uchar4 t01 = right ? idx[o00 + CV] : none;
-      const float4 d01 = right ? dout[o00 + CV] : z4;
-      const uchar4 t10 = down ? idx[o00 + Wo * CV] : none;
-      const float4 d10 = down ? dout[o00 + Wo * CV] : z4;
-      const uchar4 t11 = (down && right) ? idx[o00 + (Wo + 1) * CV] : none;
-      const float4 d11 = (down && right) ? dout[o00 + (Wo + 1) * CV] : z4;
+      float4 g[4];
+      pool_bwd_gather2x2(dout, idx, obase + (i * Wo + j) * CV + c4, CV, Wo, right, down, g);
       const int64_t p00 = ibase + ((2 * i) * W + 2 * j) * CV + c4;
-      float4 g = z4;                      // (2i, 2j): centre of window (i,j)
-      pool_take(g, t00, d00, 4);
-      dx[p00] = g;
-      if (w1ok) {                         // (2i, 2j+1): (r=1,s=0) of (i,j+1), then (1,2) of (i,j)
-        g = z4;
-        pool_take(g, t01, d01, 3);
-        pool_take(g, t00, d00, 5);
-        dx[p00 + CV] = g;
-      }
-      if (h1ok) {                         // (2i+1, 2j): (0,1) of (i+1,j), then (2,1) of (i,j)
-        g = z4;
-        pool_take(g, t10, d10, 1);
-        pool_take(g, t00, d00, 7);
-        dx[p00 + W * CV] = g;
-        if (w1ok) {                       // (2i+1, 2j+1): (0,0) of (i+1,j+1), (0,2) of (i+1,j), (2,0) of (i,j+1), (2,2) of (i,j)
-          g = z4;
-          pool_take(g, t11, d11, 0);
-          pool_take(g, t10, d10, 2);
-          pool_take(g, t01, d01, 6);
-          pool_take(g, t00, d00, 8);
-          dx[p00 + (W + 1) * CV] = g;
-        }
+      dx[p00] = g[0];
+      if (w1ok) dx[p00 + CV] = g[1];
+      if (h1ok) {
+        dx[p00 + W * CV] = g[2];
+        if (w1ok) dx[p00 + (W + 1) * CV] = g[3];
       }
     }
   }

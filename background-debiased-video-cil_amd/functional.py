@@ -182,8 +182,8 @@ class StemFn(torch.autograd.Function):
             raise NotImplementedError('backward through eval-mode BatchNorm is not implemented (norm_eval=False in all CIL configs)')
         x4, gamma, y, mask, idx, mean, invstd = ctx.saved_tensors
         dp = dp if dp.is_contiguous() else dp.contiguous()
-        da = K.maxpool_bwd(dp, idx, ctx.a_shape)
-        dy, dgamma, dbeta = K.bn_backward(da, mask, y, gamma, mean, invstd, True)
+        # max-pool backward + BN/ReLU backward in one go: the 822 MB gradient of the stem activation is never written
+        dy, dgamma, dbeta = K.bn_backward_maxpool(dp, idx, mask, y, gamma, mean, invstd)
         dw = None
         if ctx.needs_input_grad[1]:
             dw4 = K.conv_wgrad(dy, x4, ctx.g)

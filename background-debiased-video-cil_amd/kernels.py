@@ -272,6 +272,27 @@ def bn_backward(dout, relu_mask, y, gamma, save_mean, save_invstd, relu, dgamma=
     return (coef if reduce_only else d), dgamma, dbeta
 
 
+def bn_backward_maxpool(dpool, pool_idx, relu_mask, y, gamma, save_mean, save_invstd):
+    """BN(+ReLU) backward behind MaxPool2d(3,2,1) (the stem): the pooled gradient is expanded on the fly.
+    -> (dy, dgamma, dbeta)."""
+    _chk(y, name='y')
+    N, H, W, C = y.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    _chk(dpool, (N, Ho, Wo, C), name='dpool')
+    _chk(pool_idx, (N, Ho, Wo, C), dtype=torch.uint8, name='pool_idx')
+    _chk(relu_mask, (y.numel() // 32,), dtype=torch.int32, name='relu_mask')
+    for t, n in ((gamma, 'gamma'), (save_mean, 'save_mean'), (save_invstd, 'save_invstd')):
+        _chk(t, (C,), name=n)
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
+    ws = _bn_ws(N * H * W, C, y.device)
+    check(lib().bdv_bn_backward_maxpool(_p(dpool), _p(pool_idx), _p(relu_mask), _p(y), _p(gamma), _p(save_mean), _p(save_invstd),
+                                        _p(dy), _p(dgamma), _p(dbeta), 0.0, N, H, W, C, _p(ws), ws.numel(), _stream()),
+          'bdv_bn_backward_maxpool')
+    return dy, dgamma, dbeta
+
+
 def relu_bwd(dout, relu_mask, add=None, g=None):
     _chk(dout, name='dout')
     _chk(relu_mask, (dout.numel() // 32,), dtype=torch.int32, name='relu_mask')

@@ -161,6 +161,13 @@ int bdv_maxpool_bwd(const float* dout, const uint8_t* idx, float* dx, int N, int
 /* Stem tail of a training forward in one pass (UPSTREAM ConvModule norm+act, then ResNet.maxpool): a = relu(y * scale +
  * shift), out = maxpool(a), idx as bdv_maxpool_fwd, relu_mask = 1 bit per element of a (a > 0) as bdv_bn_apply writes it.
  * The activation a itself is not materialised. */
+/* Backward of the same stem tail: BatchNorm(+ReLU) backward whose incoming gradient is the MaxPool2d(3,2,1) backward of
+ * dpool [N,Ho,Wo,C]; that gradient is gathered on the fly in both passes (statistics, apply) and never materialised.
+ * dy [N,H,W,C]; dgamma/dbeta as bdv_bn_backward; workspace = bdv_bn_workspace_bytes(N*H*W, C). */
+int bdv_bn_backward_maxpool(const float* dpool, const uint8_t* pool_idx, const uint32_t* relu_mask, const float* y,
+                            const float* gamma, const float* save_mean, const float* save_invstd, float* dy, float* dgamma,
+                            float* dbeta, float beta_acc, int N, int H, int W, int C, void* workspace,
+                            size_t workspace_bytes, void* stream);
 int bdv_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, uint8_t* idx,
                             uint32_t* relu_mask, int N, int H, int W, int C, void* stream);
 /* UPSTREAM TSMHead.avg_pool = AdaptiveAvgPool2d(1): [N,HW,C] -> [N,C] */

@@ -310,3 +310,24 @@ def test_bn_relu_maxpool_fused_equals_separate_kernels(shape, dev):
     assert torch.equal(out, out_ref)
     assert torch.equal(idx, idx_ref)
     assert torch.equal(mask, mask_ref)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64), (3, 15, 11, 64), (4, 112, 112, 64), (1, 9, 14, 128)])
+def test_bn_backward_behind_maxpool_equals_separate_kernels(shape, dev):
+    """Stem backward without the expanded pooling gradient == maxpool_bwd followed by bn_backward."""
+    from bdvcil_amd import kernels as K
+    g = torch.Generator().manual_seed(19)
+    y = torch.randn(*shape, generator=g).to(dev)
+    C = shape[-1]
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=g) * 0.3).to(dev)
+    mean, invstd, scale, shift = K.bn_train_stats(y, gamma, beta, 1e-5, 0.1, None, None)
+    p, idx, mask = K.bn_relu_maxpool_fwd(y, scale, shift)
+    dp = torch.randn(p.shape, generator=g).to(dev)
+    da = K.maxpool_bwd(dp, idx, shape)
+    dy_ref, dg_ref, db_ref = K.bn_backward(da, mask, y, gamma, mean, invstd, True)
+    dy, dg, db = K.bn_backward_maxpool(dp, idx, mask, y, gamma, mean, invstd)
+    torch.cuda.synchronize()
+    _close(dy, dy_ref, tol=2e-5)
+    _close(dg, dg_ref, tol=2e-5, atol=1e-4)
+    _close(db, db_ref, tol=2e-5, atol=1e-4)

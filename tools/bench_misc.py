@@ -32,3 +32,12 @@ def separate():
     return K.maxpool_fwd(a_)
 print('stem tail separate (bn_apply + maxpool_fwd) %.1f us' % timeit(separate))
 print('stem tail fused    (bn_relu_maxpool_fwd)    %.1f us' % timeit(lambda: K.bn_relu_maxpool_fwd(yy, sc, sh)))
+gam = torch.rand(64, device=dev) + 0.5; bet = torch.zeros(64, device=dev)
+mean_, invstd_, sc_, sh_ = K.bn_train_stats(yy, gam, bet, 1e-5, 0.1, None, None)
+pp, ii, mm = K.bn_relu_maxpool_fwd(yy, sc_, sh_)
+dpp = torch.randn_like(pp)
+def sep_bwd():
+    da_ = K.maxpool_bwd(dpp, ii, tuple(yy.shape))
+    return K.bn_backward(da_, mm, yy, gam, mean_, invstd_, True)
+print('stem backward separate (maxpool_bwd + bn_backward) %.1f us' % timeit(sep_bwd))
+print('stem backward fused    (bn_backward_maxpool)       %.1f us' % timeit(lambda: K.bn_backward_maxpool(dpp, ii, mm, yy, gam, mean_, invstd_)))
