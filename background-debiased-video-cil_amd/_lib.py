@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lib = None
 
@@ -60,7 +60,7 @@ SIGNATURES = {
     'bdv_bn_train_stats': (c_int, [P, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_size_t, P]),
     'bdv_bn_train_finalize': (c_int, [P, c_int, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P]),
     'bdv_bn_eval_params': (c_int, [c_int, P, P, P, P, c_float, P, P, P]),
-    'bdv_bn_apply': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, P]),
+    'bdv_bn_apply': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, P]),
     'bdv_bn_backward': (c_int, [P, P, P, P, P, P, P, P, P, P, c_float, c_int64, c_int, c_int, P, c_int, P, c_size_t, P]),
     'bdv_bn_backward_maxpool': (c_int, [P, P, P, P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'bdv_relu_bwd': (c_int, [P, P, P, P, c_int64, P]),

@@ -163,9 +163,12 @@ __device__ __forceinline__ float4 apply_nibble(float4 g, unsigned nib) {
   return g;
 }
 
+// res_scale / res_shift (optional): the residual is itself a raw conv output that still needs its own BatchNorm
+// (the downsample branch of a block): r = res * res_scale + res_shift is formed here instead of in a pass of its own.
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
                                                         const float4* __restrict__ shift, const float4* __restrict__ res,
+                                                        const float4* __restrict__ res_scale, const float4* __restrict__ res_shift,
                                                         float4* __restrict__ out, uint32_t* __restrict__ mask, int64_t n4, int CV) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   // n4 is a multiple of 8 (C % 32 == 0) and so is the stride: the 8 lanes of one mask word stay together
@@ -178,7 +181,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
     o.z = v.z * sc.z + sh.z;
     o.w = v.w * sc.w + sh.w;
     if (RES) {
-      const float4 r = res[i];
+      float4 r = res[i];
+      if (res_scale != nullptr) {
+        const float4 rs = res_scale[c4], rb = res_shift[c4];
+        r.x = r.x * rs.x + rb.x; r.y = r.y * rs.y + rb.y; r.z = r.z * rs.z + rb.z; r.w = r.w * rs.w + rb.w;
+      }
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
     if (RELU) {
@@ -439,9 +446,12 @@ extern "C" int bdv_bn_eval_params(int C, const float* gamma, const float* beta, 
   return BDV_OK;
 }
 
-extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shift, const float* res, float* out,
-                            uint32_t* relu_mask, int64_t M, int C, int relu, void* stream) {
+extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale,
+                            const float* res_shift, float* out, uint32_t* relu_mask, int64_t M, int C, int relu, void* stream) {
   BDV_REQUIRE(y && scale && shift && out, "bdv_bn_apply: null pointer");
+  BDV_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (res_scale == nullptr || res != nullptr),
+              "bdv_bn_apply: res_scale and res_shift come together and need res");
+  BDV_REQUIRE(bdv_aligned16(res_scale) && bdv_aligned16(res_shift), "bdv_bn_apply: alignment");
   BDV_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bdv_bn_apply: bad shape");
   BDV_REQUIRE(relu_mask == nullptr || (relu && C % 32 == 0), "bdv_bn_apply: relu_mask needs relu and C %% 32 == 0");
   BDV_REQUIRE(bdv_aligned16(y) && bdv_aligned16(out) && bdv_aligned16(scale) && bdv_aligned16(shift) &&
@@ -451,11 +461,12 @@ extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shi
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(ew_grid(n4)), blk(256);
   const float4 *y4 = (const float4*)y, *sc = (const float4*)scale, *sh = (const float4*)shift, *r4 = (const float4*)res;
+  const float4 *rs = (const float4*)res_scale, *rb = (const float4*)res_shift;
   float4* o4 = (float4*)out;
-  if (relu && res) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, blk, 0, s, y4, sc, sh, r4, o4, relu_mask, n4, CV);
-  else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, blk, 0, s, y4, sc, sh, r4, o4, relu_mask, n4, CV);
-  else if (res) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, blk, 0, s, y4, sc, sh, r4, o4, relu_mask, n4, CV);
-  else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, blk, 0, s, y4, sc, sh, r4, o4, relu_mask, n4, CV);
+  if (relu && res) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, blk, 0, s, y4, sc, sh, r4, rs, rb, o4, relu_mask, n4, CV);
+  else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, blk, 0, s, y4, sc, sh, r4, rs, rb, o4, relu_mask, n4, CV);
+  else if (res) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, blk, 0, s, y4, sc, sh, r4, rs, rb, o4, relu_mask, n4, CV);
+  else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, blk, 0, s, y4, sc, sh, r4, rs, rb, o4, relu_mask, n4, CV);
   BDV_LAUNCH_CHECK("bdv_bn_apply");
   return BDV_OK;
 }

@@ -208,12 +208,13 @@ def _block_forward(x, blk, training, params, save):
         wd, gd, bd = params[3 * n_main:3 * n_main + 3]
         g = u.geom(N, H, W)
         if training:
-            yd, mean_d, invstd_d, sc, sh = _conv_bn_forward(x, weight_krsc(wd), g, bns[n_main], gd, bd, training)
-            identity = K.bn_apply(yd, sc, sh, None, False)
+            # the downsample BatchNorm is applied inside the block-output kernel (res_affine): no identity tensor
+            yd, mean_d, invstd_d, sc_d, sh_d = _conv_bn_forward(x, weight_krsc(wd), g, bns[n_main], gd, bd, training)
+            identity, id_affine = yd, (sc_d, sh_d)
         else:
-            identity = _conv_bn_eval(x, weight_krsc(wd), g, bns[n_main], gd, bd, None, False)
+            identity, id_affine = _conv_bn_eval(x, weight_krsc(wd), g, bns[n_main], gd, bd, None, False), None
     else:
-        identity = x
+        identity, id_affine = x, None
     cur = x
     h, w_ = H, W
     for i in range(n_main):
@@ -228,10 +229,11 @@ def _block_forward(x, blk, training, params, save):
             continue
         y, mean, invstd, sc, sh = _conv_bn_forward(cur, weight_krsc(wt), g, bns[i], gm, bt, training)
         if save:
-            a, mask = K.bn_apply(y, sc, sh, identity if last else None, True, want_mask=True)
+            a, mask = K.bn_apply(y, sc, sh, identity if last else None, True, want_mask=True,
+                                 res_affine=id_affine if last else None)
             saved += [y, a, mean, invstd, mask]
         else:
-            a = K.bn_apply(y, sc, sh, identity if last else None, True)
+            a = K.bn_apply(y, sc, sh, identity if last else None, True, res_affine=id_affine if last else None)
         cur = a
         h, w_ = g.Ho, g.Wo
     if save and has_down:

@@ -213,8 +213,9 @@ def bn_eval_params(gamma, beta, running_mean, running_var, eps):
     return ss[0], ss[1]
 
 
-def bn_apply(y, scale, shift, res=None, relu=True, out=None, want_mask=False):
-    """-> out, or (out, relu_mask) when want_mask (int32 tensor, 1 bit per element: out > 0)."""
+def bn_apply(y, scale, shift, res=None, relu=True, out=None, want_mask=False, res_affine=None):
+    """-> out, or (out, relu_mask) when want_mask (int32 tensor, 1 bit per element: out > 0).
+    ``res_affine = (scale, shift)``: the residual is a raw conv output and gets its own BatchNorm here."""
     C = y.shape[-1]
     M = y.numel() // C
     _chk(y, name='y')
@@ -222,6 +223,13 @@ def bn_apply(y, scale, shift, res=None, relu=True, out=None, want_mask=False):
     _chk(shift, (C,), name='shift')
     if res is not None:
         _chk(res, tuple(y.shape), name='res')
+    rs = rb = None
+    if res_affine is not None:
+        if res is None:
+            raise ValueError('bn_apply: res_affine needs res')
+        rs, rb = res_affine
+        _chk(rs, (C,), name='res_scale')
+        _chk(rb, (C,), name='res_shift')
     o = out if out is not None else torch.empty_like(y)
     _chk(o, tuple(y.shape), name='out')
     mask = None
@@ -229,8 +237,8 @@ def bn_apply(y, scale, shift, res=None, relu=True, out=None, want_mask=False):
         if not relu or C % 32 != 0:
             raise ValueError('bn_apply: a ReLU mask needs relu=True and C % 32 == 0')
         mask = torch.empty(y.numel() // 32, dtype=torch.int32, device=y.device)
-    check(lib().bdv_bn_apply(_p(y), _p(scale), _p(shift), _p(res), _p(o), _p(mask), M, C, int(bool(relu)), _stream()),
-          'bdv_bn_apply')
+    check(lib().bdv_bn_apply(_p(y), _p(scale), _p(shift), _p(res), _p(rs), _p(rb), _p(o), _p(mask), M, C, int(bool(relu)),
+                             _stream()), 'bdv_bn_apply')
     return (o, mask) if want_mask else o
 
 

@@ -129,11 +129,13 @@ int bdv_bn_train_finalize(const float* partial, int rows, int64_t M, int C, cons
 /* eval: scale/shift from running statistics. */
 int bdv_bn_eval_params(int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, void* stream);
-/* out = act(y*scale[c] + shift[c] + (res ? res : 0)), act = ReLU if relu != 0.  relu_mask (optional, needs
- * C % 32 == 0): bit e of relu_mask[] = (out[e] > 0) for flat element index e -- the 1-bit-per-element ReLU sign
- * mask the backward kernels read instead of the fp32 activation. */
-int bdv_bn_apply(const float* y, const float* scale, const float* shift, const float* res, float* out,
-                 uint32_t* relu_mask, int64_t M, int C, int relu, void* stream);
+/* out = act(y*scale[c] + shift[c] + r), act = ReLU if relu != 0; r = 0 without res, res itself, or -- with
+ * res_scale/res_shift -- res*res_scale[c] + res_shift[c] (the block's downsample conv output gets its own BatchNorm
+ * here instead of in a separate pass).  relu_mask (optional, needs C % 32 == 0): bit e of relu_mask[] = (out[e] > 0)
+ * for flat element index e -- the 1-bit-per-element ReLU sign mask the backward kernels read instead of the fp32
+ * activation. */
+int bdv_bn_apply(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale,
+                 const float* res_shift, float* out, uint32_t* relu_mask, int64_t M, int C, int relu, void* stream);
 /* backward of (BN-train -> +res -> ReLU): g = dout * (relu_mask bit if relu), dgamma = sum g*xhat,
  * dbeta = sum g, dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).  dgamma/dbeta are written as
  * beta_acc*old + new.  The residual-path gradient is g itself; consumers re-derive it from

@@ -331,3 +331,19 @@ def test_bn_backward_behind_maxpool_equals_separate_kernels(shape, dev):
     _close(dy, dy_ref, tol=2e-5)
     _close(dg, dg_ref, tol=2e-5, atol=1e-4)
     _close(db, db_ref, tol=2e-5, atol=1e-4)
+
+
+def test_bn_apply_with_batchnorm_on_the_residual(dev):
+    """res_affine: out = relu(y*s + b + (res*rs + rb)) == applying the residual's BatchNorm in a separate pass."""
+    from bdvcil_amd import kernels as K
+    g = torch.Generator().manual_seed(23)
+    M, C = 1000, 256
+    y, r = torch.randn(M, C, generator=g).to(dev), torch.randn(M, C, generator=g).to(dev)
+    s, b, rs, rb = [torch.randn(C, generator=g).to(dev) for _ in range(4)]
+    ident = K.bn_apply(r, rs, rb, None, False)
+    ref, mref = K.bn_apply(y, s, b, ident, True, want_mask=True)
+    out, mask = K.bn_apply(y, s, b, r, True, want_mask=True, res_affine=(rs, rb))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(mask, mref)
+    with pytest.raises(ValueError):
+        K.bn_apply(y, s, b, None, True, res_affine=(rs, rb))
