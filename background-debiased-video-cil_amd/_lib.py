@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _lib = None
 
@@ -40,11 +40,6 @@ class BnStatFuse(Structure):
     _fields_ = [('y', c_void_p), ('relu_mask', c_void_p), ('mean', c_void_p), ('invstd', c_void_p), ('partial', c_void_p)]
 
 
-class BnBwdFuse(Structure):
-    """Mirror of ``bdv_bn_bwd_fuse``."""
-    _fields_ = [('dout', c_void_p), ('relu_mask', c_void_p), ('y', c_void_p), ('coef', c_void_p), ('dy_out', c_void_p)]
-
-
 
 # name -> (restype, argtypes)
 SIGNATURES = {
@@ -55,13 +50,13 @@ SIGNATURES = {
     'bdv_conv_fprop': (c_int, [P, P, P, POINTER(ConvGeom), P, POINTER(ConvAffine), P, c_size_t, P]),
     'bdv_conv_dgrad_stat_rows': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_dgrad': (c_int, [P, P, P, P, P, POINTER(ConvGeom), POINTER(BnStatFuse), P, c_size_t, P]),
-    'bdv_conv_wgrad': (c_int, [P, P, P, c_float, POINTER(ConvGeom), POINTER(BnBwdFuse), P, c_size_t, P]),
+    'bdv_conv_wgrad': (c_int, [P, P, P, c_float, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_bn_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'bdv_bn_train_stats': (c_int, [P, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_size_t, P]),
     'bdv_bn_train_finalize': (c_int, [P, c_int, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P]),
     'bdv_bn_eval_params': (c_int, [c_int, P, P, P, P, c_float, P, P, P]),
     'bdv_bn_apply': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, P]),
-    'bdv_bn_backward': (c_int, [P, P, P, P, P, P, P, P, P, P, c_float, c_int64, c_int, c_int, P, c_int, P, c_size_t, P]),
+    'bdv_bn_backward': (c_int, [P, P, P, P, P, P, P, P, P, c_float, c_int64, c_int, c_int, P, c_int, P, c_size_t, P]),
     'bdv_bn_backward_maxpool': (c_int, [P, P, P, P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'bdv_relu_bwd': (c_int, [P, P, P, P, c_int64, P]),
     'bdv_add': (c_int, [P, P, P, c_int64, P]),

@@ -249,8 +249,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int RB,
                                                                int64_t M, int C, const float* __restrict__ gamma,
                                                                const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, float beta_acc, float* __restrict__ coef,
-                                                               const float* __restrict__ mean, float* __restrict__ fused) {
+                                                               float* __restrict__ dbeta, float beta_acc, float* __restrict__ coef) {
   __shared__ double sh[2][64][5];
   const int c = blockIdx.x * 4 + (threadIdx.x & 3), rl = threadIdx.x >> 2;
   double s1, s2;
@@ -262,12 +261,6 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   coef[c] = a;
   coef[C + c] = (float)(s1 / (double)M);
   coef[2 * C + c] = (float)(s2 / (double)M);
-  if (fused != nullptr) {  // dy = A*g - Bc*(y - mean) - Cc, consumed by the conv dgrad / wgrad operand loaders
-    fused[c] = a;
-    fused[C + c] = (float)((double)a * (double)invstd[c] * (s2 / (double)M));
-    fused[2 * C + c] = (float)((double)a * (s1 / (double)M));
-    fused[3 * C + c] = mean[c];
-  }
 }
 
 template <bool RELU>
@@ -472,16 +465,15 @@ extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shi
 }
 
 extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, const float* y, const float* gamma,
-                               const float* save_mean, const float* save_invstd, float* dy, float* fused_coef, float* dgamma,
+                               const float* save_mean, const float* save_invstd, float* dy, float* dgamma,
                                float* dbeta, float beta_acc, int64_t M, int C, int relu, const float* stat_partial,
                                int stat_rows, void* workspace, size_t workspace_bytes, void* stream) {
-  BDV_REQUIRE(dout && y && gamma && save_mean && save_invstd && workspace, "bdv_bn_backward: null pointer");
+  BDV_REQUIRE(dout && y && gamma && save_mean && save_invstd && dy && workspace, "bdv_bn_backward: null pointer");
   BDV_REQUIRE(stat_partial == nullptr || (stat_rows > 0 && bdv_aligned16(stat_partial)), "bdv_bn_backward: bad stat_partial");
-  BDV_REQUIRE(dy || fused_coef, "bdv_bn_backward: give dy and/or fused_coef");
   BDV_REQUIRE(!relu || (relu_mask && C % 32 == 0), "bdv_bn_backward: relu needs the forward ReLU mask (C %% 32 == 0)");
   BDV_REQUIRE(M > 0 && bn_c_ok(C), "bdv_bn_backward: unsupported M=%lld C=%d", (long long)M, C);
   BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(y) && bdv_aligned16(dy) && bdv_aligned16(workspace) &&
-                  bdv_aligned16(save_mean) && bdv_aligned16(save_invstd) && bdv_aligned16(fused_coef), "bdv_bn_backward: alignment");
+                  bdv_aligned16(save_mean) && bdv_aligned16(save_invstd), "bdv_bn_backward: alignment");
   if (workspace_bytes < bdv_bn_workspace_bytes(M, C)) {
     bdv_set_error("bdv_bn_backward: workspace too small");
     return BDV_EWORKSPACE;
@@ -507,9 +499,8 @@ extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, con
     BDV_LAUNCH_CHECK("bdv_bn_backward(partial)");
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, q1, q2, rows, M, C, gamma, save_invstd, dgamma,
-                     dbeta, beta_acc, coef, save_mean, fused_coef);
+                     dbeta, beta_acc, coef);
   BDV_LAUNCH_CHECK("bdv_bn_backward(finalize)");
-  if (dy == nullptr) return BDV_OK;
   const int64_t n4 = M * C / 4;
   const dim3 grid(ew_grid(n4)), blk(256);
   if (relu)
@@ -556,7 +547,7 @@ extern "C" int bdv_bn_backward_maxpool(const float* dpool, const uint8_t* pool_i
                      (float4*)nullptr, p1, p2, N, H, W, CV, Ho, Wo);
   BDV_LAUNCH_CHECK("bdv_bn_backward_maxpool(partial)");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)p1, (const float*)p2, gx * gy, M, C,
-                     gamma, save_invstd, dgamma, dbeta, beta_acc, coef, save_mean, (float*)nullptr);
+                     gamma, save_invstd, dgamma, dbeta, beta_acc, coef);
   BDV_LAUNCH_CHECK("bdv_bn_backward_maxpool(finalize)");
   hipLaunchKernelGGL((bn_bwd_pool_kernel<true>), grid, blk, 0, s, (const float4*)dpool, (const uchar4*)pool_idx, relu_mask,
                      (const float4*)y, (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy,

@@ -894,21 +894,11 @@ __global__ __launch_bounds__(256) void conv_dgrad_fixup_kernel(const float* __re
 // =========================================================================================
 // wgrad: slab[split][co][tap*Cin + ci] = sum_{m in split} dy[m, co] * x_shift[pix(m, tap), ci]
 // Both operands are M-contiguous (16-byte direct LDS stores).  C4 = stem (Cin = 4, one tap per 16-byte load).
-// FBN: the BatchNorm(+ReLU) backward apply step is done here: `dy` is then the gradient w.r.t. the BN/ReLU output
-// and the A tile is  dy = A*(dout & mask) - Bc*(y - mean) - Cc  formed in registers between the global load and the
-// LDS store; the blocks of the first N tile also write it to bn.dy_out for the dgrad kernel.
 // =========================================================================================
-struct BnFuse {
-  const float* y;
-  const uint32_t* mask;
-  const float* coef;
-  float* dy_out;
-};
-
-template <int BM, int BN, int WM, int WN, bool C4, bool FBN, bool INCR>
+template <int BM, int BN, int WM, int WN, bool C4, bool INCR>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           float* __restrict__ slab, Geom g, int MTw, int NTw,
-                                                          int kt_per_split, BnFuse bn) {
+                                                          int kt_per_split) {
   constexpr int LDA = BM, LDB = BN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
@@ -942,23 +932,6 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
     const int krow = idx / AV, c4 = idx - krow * AV;
     a_off[p] = (krow * g.Cout + mt * BM + 4 * c4) * 4;
   }
-  // fused BatchNorm backward: the thread's 4 channels are fixed over the K loop (256 % AV == 0)
-  const int a_col = mt * BM + 4 * (tid % AV);
-  const int a_krow0 = tid / AV;
-  float4 cA, cB, cC, cM;
-  __amdgpu_buffer_rsrc_t y2r, mkr;
-  const bool has_mask = FBN && bn.mask != nullptr;
-  if (FBN) {
-    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)bn.coef, 0, 4 * g.Cout * 4, 0x00020000);
-    cA = buf_load16(cr, a_col * 4, 0);
-    cB = buf_load16(cr, (g.Cout + a_col) * 4, 0);
-    cC = buf_load16(cr, (2 * g.Cout + a_col) * 4, 0);
-    cM = buf_load16(cr, (3 * g.Cout + a_col) * 4, 0);
-    y2r = __builtin_amdgcn_make_buffer_rsrc((void*)bn.y, 0, g.M * g.Cout * 4, 0x00020000);
-    mkr = __builtin_amdgcn_make_buffer_rsrc((void*)(has_mask ? bn.mask : (const uint32_t*)bn.y), 0,
-                                            has_mask ? g.M * (g.Cout / 8) : 0, 0x00020000);
-  }
-  const int mbit = (4 * (tid % AV)) & 31;  // Cout % 64 == 0: the bit position does not depend on the row
   // B: column -> (tap, ci) for this thread's loads (fixed over the K loop)
   int b_krow[BP], b_off[BP], b_r[BP], b_s[BP], b_cls[BP];
   bool b_cok[BP];
@@ -1017,19 +990,11 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
   }
 
   float4 ra[AP], rb[BP];
-  float4 ry[FBN ? AP : 1];
-  uint32_t rm[FBN ? AP : 1];
   auto load = [&](int kt) {
     const int m0 = kt * BK;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) {  // rows past M lie past num_records (the range check covers the vector offset): zeros
-      const int off = a_off[p] + m0 * g.Cout * 4;
-      ra[p] = buf_load16(yr, off, 0);
-      if (FBN) {
-        ry[p] = buf_load16(y2r, off, 0);
-        rm[p] = has_mask ? __builtin_amdgcn_raw_buffer_load_b32(mkr, (off >> 7) << 2, 0, 0) : 0xffffffffu;
-      }
-    }
+    for (int p = 0; p < AP; ++p)  // rows past M lie past num_records (the range check covers the vector offset): zeros
+      ra[p] = buf_load16(yr, a_off[p] + m0 * g.Cout * 4, 0);
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
       const int m = m0 + b_krow[p];
@@ -1071,21 +1036,6 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
   if (kt_begin < kt_end) {
     load(kt_begin);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-      if (FBN) {
-#pragma unroll
-        for (int p = 0; p < AP; ++p) {
-          const int m = kt * BK + a_krow0 + (256 / AV) * p;
-          const uint32_t mk = rm[p] >> mbit;
-          float4 v;
-          v.x = cA.x * ((mk & 1u) ? ra[p].x : 0.f) - cB.x * (ry[p].x - cM.x) - cC.x;
-          v.y = cA.y * ((mk & 2u) ? ra[p].y : 0.f) - cB.y * (ry[p].y - cM.y) - cC.y;
-          v.z = cA.z * ((mk & 4u) ? ra[p].z : 0.f) - cB.z * (ry[p].z - cM.z) - cC.z;
-          v.w = cA.w * ((mk & 8u) ? ra[p].w : 0.f) - cB.w * (ry[p].w - cM.w) - cC.w;
-          if (m >= g.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
-          ra[p] = v;
-          if (nt == 0 && m < g.M) *reinterpret_cast<float4*>(bn.dy_out + (size_t)m * g.Cout + a_col) = v;
-        }
-      }
       __syncthreads();
       store_direct<LDA, BM, AP>(As, ra, tid);
       store_direct<LDB, BN, BP>(Bs, rb, tid);
@@ -1472,26 +1422,11 @@ extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const 
 }
 
 extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float beta, const bdv_conv_geom* gg,
-                              const bdv_bn_bwd_fuse* bn, void* workspace, size_t workspace_bytes, void* stream) {
+                              void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_wgrad")) return e;
-  BDV_REQUIRE(x && dw && workspace, "bdv_conv_wgrad: null pointer");
+  BDV_REQUIRE(dy && x && dw && workspace, "bdv_conv_wgrad: null pointer");
   BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(dw) && bdv_aligned16(workspace),
               "bdv_conv_wgrad: pointers must be 16-byte aligned");
-  BnFuse bf = {nullptr, nullptr, nullptr, nullptr};
-  if (bn != nullptr) {
-    BDV_REQUIRE(dy == nullptr, "bdv_conv_wgrad: dy must be NULL when the BatchNorm backward is fused (dy is produced)");
-    BDV_REQUIRE(bn->dout && bn->y && bn->coef && bn->dy_out, "bdv_conv_wgrad: null pointer in bdv_bn_bwd_fuse");
-    BDV_REQUIRE(bdv_aligned16(bn->dout) && bdv_aligned16(bn->y) && bdv_aligned16(bn->coef) && bdv_aligned16(bn->dy_out) &&
-                    bdv_aligned16(bn->relu_mask), "bdv_conv_wgrad: bdv_bn_bwd_fuse pointers must be 16-byte aligned");
-    BDV_REQUIRE(gg->Cin % BK == 0, "bdv_conv_wgrad: fused BatchNorm backward is not available for the Cin = 4 stem");
-    dy = bn->dout;
-    bf.y = bn->y;
-    bf.mask = bn->relu_mask;
-    bf.coef = bn->coef;
-    bf.dy_out = bn->dy_out;
-  } else {
-    BDV_REQUIRE(dy != nullptr, "bdv_conv_wgrad: null pointer");
-  }
   const WgradPlan p = plan_wgrad(gg);
   const size_t need = (size_t)p.splits * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(float);
   if (workspace_bytes < need) {
@@ -1508,24 +1443,21 @@ extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float 
     fprintf(stderr, "[bdv plan] wgrad %dx%d Cin %d Cout %d k%d s%d: tiles %d -> splits %d x %d k-iters (%s)\n", gg->H, gg->W,
             gg->Cin, gg->Cout, gg->R, gg->stride, p.MTw * p.NTw, p.splits, p.kt_per_split, p.small ? "64x64" : "128x128");
   const bool incr = g.Ho * g.Wo > BK && BK / g.Wo + 1 <= g.Ho;
-#define BDV_WGRAD(BMN, C4F, FBNF)                                                                                              \
+#define BDV_WGRAD(BMN, C4F)                                                                                                    \
   do {                                                                                                                         \
     if (incr)                                                                                                                  \
-      hipLaunchKernelGGL((conv_wgrad_kernel<BMN, BMN, 2, 2, C4F, FBNF, true>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw, \
-                         p.kt_per_split, bf);                                                                                  \
+      hipLaunchKernelGGL((conv_wgrad_kernel<BMN, BMN, 2, 2, C4F, true>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,   \
+                         p.kt_per_split);                                                                                      \
     else                                                                                                                       \
-      hipLaunchKernelGGL((conv_wgrad_kernel<BMN, BMN, 2, 2, C4F, FBNF, false>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw,    \
-                         p.NTw, p.kt_per_split, bf);                                                                           \
+      hipLaunchKernelGGL((conv_wgrad_kernel<BMN, BMN, 2, 2, C4F, false>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,  \
+                         p.kt_per_split);                                                                                      \
   } while (0)
-  if (bn != nullptr) {
-    if (!p.small) BDV_WGRAD(128, false, true);
-    else BDV_WGRAD(64, false, true);
-  } else if (!p.small) {
-    BDV_WGRAD(128, false, false);
+  if (!p.small) {
+    BDV_WGRAD(128, false);
   } else if (p.c4) {
-    BDV_WGRAD(64, true, false);
+    BDV_WGRAD(64, true);
   } else {
-    BDV_WGRAD(64, false, false);
+    BDV_WGRAD(64, false);
   }
 #undef BDV_WGRAD
   BDV_LAUNCH_CHECK("bdv_conv_wgrad");

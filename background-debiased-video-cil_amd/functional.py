@@ -35,11 +35,6 @@ import os as _os
 _SIDE = {'enabled': _os.environ.get('BDVCIL_WGRAD_SIDE_STREAM', '0') != '0', 'streams': {}, 'pending': {}}
 
 
-# BatchNorm backward apply step inside the wgrad kernel (bdv_conv_wgrad with a bdv_bn_bwd_fuse).  It removes the
-# separate apply kernel (3 passes over the conv output) but the wgrad then reads two tensors instead of one and writes
-# dy, i.e. it only saves one pass in four, and the heavier loader costs the wgrad kernels more than that on MI355X
-# (measured on TSM-R50 bs32: 395 clips/s fused vs 400 unfused).  Off by default; BDVCIL_FUSE_BN_BWD=1 enables it.
-FUSE_BN_BWD = _os.environ.get('BDVCIL_FUSE_BN_BWD', '0') != '0'
 # BatchNorm-backward statistics of a unit taken in the epilogue of the dgrad that produces its output gradient
 # (bdv_conv_dgrad with a bdv_bn_stat_fuse): removes the separate pass over dout, y and the mask for the inner units.
 FUSE_BN_STATS = _os.environ.get('BDVCIL_FUSE_BN_STATS', '1') != '0'
@@ -136,14 +131,7 @@ def _conv_bn_eval(x, w_krsc, g, bn, gamma, beta, res, relu):
 
 
 def _bn_wgrad_backward(dout, mask, y, gamma, mean, invstd, inp, geom, need_dw, stat_partial=None):
-    """BatchNorm(+ReLU) backward of one conv+BN unit followed by the conv's wgrad -> (dy, dgamma, dbeta, dw | None).
-    With a weight gradient wanted (and no side stream) only the BN reductions run as their own kernels; the
-    elementwise apply step happens inside the wgrad kernel, which also writes dy for the dgrad."""
-    if need_dw and not _SIDE['enabled'] and FUSE_BN_BWD:
-        coef, dg, db = K.bn_backward(dout, mask, y, gamma, mean, invstd, True, reduce_only=True, stat_partial=stat_partial)
-        dy = torch.empty_like(y)
-        dw = K.conv_wgrad(None, inp, geom, bn_fuse=(dout, mask, y, coef, dy))
-        return dy, dg, db, dw
+    """BatchNorm(+ReLU) backward of one conv+BN unit followed by the conv's wgrad -> (dy, dgamma, dbeta, dw | None)."""
     dy, dg, db = K.bn_backward(dout, mask, y, gamma, mean, invstd, True, stat_partial=stat_partial)
     dw = wgrad_overlapped(dy, inp, geom) if need_dw else None
     return dy, dg, db, dw

@@ -11,7 +11,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from ._lib import BnBwdFuse, BnStatFuse, ConvAffine, ConvGeom, check, lib
+from ._lib import BnStatFuse, ConvAffine, ConvGeom, check, lib
 
 _WS = {}  # (device index, tag) -> workspace tensor (grown on demand, never shrunk)
 
@@ -129,34 +129,16 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
     return dx if bn_stats is None else (dx, partial)
 
 
-def conv_wgrad(dy: Optional[torch.Tensor], x: torch.Tensor, g: ConvGeom, dw: Optional[torch.Tensor] = None,
-               beta: float = 0.0, ws_tag: str = 'wgrad', bn_fuse=None) -> torch.Tensor:
-    """``bn_fuse = (dout, relu_mask | None, y, coef, dy_out)``: the BatchNorm(+ReLU) backward apply step runs inside
-    the kernel (``coef`` from ``bn_backward_reduce``); ``dy`` must then be None and ``dy_out`` receives it."""
-    oshape = (g.N, g.Ho, g.Wo, g.Cout)
+def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, dw: Optional[torch.Tensor] = None,
+               beta: float = 0.0, ws_tag: str = 'wgrad') -> torch.Tensor:
+    _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
     _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
     if dw is None:
-        dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=x.device)
+        dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
         beta = 0.0
     _chk(dw, (g.Cout, g.R, g.S, g.Cin), name='dw')
-    fuse = None
-    if bn_fuse is not None:
-        if dy is not None:
-            raise ValueError('conv_wgrad: dy must be None when bn_fuse is given')
-        dout, mask, y, coef, dy_out = bn_fuse
-        _chk(dout, oshape, name='dout')
-        _chk(y, oshape, name='y')
-        _chk(dy_out, oshape, name='dy_out')
-        _chk(coef, (4, g.Cout), name='coef')
-        if mask is not None:
-            _chk(mask, (y.numel() // 32,), dtype=torch.int32, name='relu_mask')
-        fuse = BnBwdFuse(dout.data_ptr(), mask.data_ptr() if mask is not None else None, y.data_ptr(), coef.data_ptr(),
-                         dy_out.data_ptr())
-    else:
-        _chk(dy, oshape, name='dy')
-    ws = _conv_ws(g, 2, x.device, ws_tag)
-    check(lib().bdv_conv_wgrad(_p(dy), _p(x), _p(dw), float(beta), ctypes.byref(g),
-                               ctypes.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), _stream()),
+    ws = _conv_ws(g, 2, dy.device, ws_tag)
+    check(lib().bdv_conv_wgrad(_p(dy), _p(x), _p(dw), float(beta), ctypes.byref(g), _p(ws), ws.numel(), _stream()),
           'bdv_conv_wgrad')
     return dw
 
@@ -243,10 +225,8 @@ def bn_apply(y, scale, shift, res=None, relu=True, out=None, want_mask=False, re
 
 
 def bn_backward(dout, relu_mask, y, gamma, save_mean, save_invstd, relu, dgamma=None, dbeta=None, beta_acc=0.0, dy=None,
-                reduce_only=False, stat_partial=None):
+                stat_partial=None):
     """Returns (dy, dgamma, dbeta).  ``relu_mask`` is the bit mask from ``bn_apply(want_mask=True)`` (needed when relu).
-    ``reduce_only``: only the reductions run and the first return value is the ``(4, C)`` coefficient table that
-    ``conv_wgrad(bn_fuse=...)`` consumes (dy is then formed inside the wgrad kernel).
     ``stat_partial``: the ``(2, rows, C)`` tile sums from ``conv_dgrad(bn_stats=...)``; the statistics pass is skipped."""
     C = y.shape[-1]
     M = y.numel() // C
@@ -262,22 +242,19 @@ def bn_backward(dout, relu_mask, y, gamma, save_mean, save_invstd, relu, dgamma=
         beta_acc = 0.0
     _chk(dgamma, (C,), name='dgamma')
     _chk(dbeta, (C,), name='dbeta')
-    if reduce_only:
-        d, coef = None, torch.empty((4, C), dtype=torch.float32, device=y.device)
-    else:
-        d, coef = (dy if dy is not None else torch.empty_like(y)), None
-        _chk(d, tuple(y.shape), name='dy')
-    ws = _bn_ws(M, C, y.device)
+    d = dy if dy is not None else torch.empty_like(y)
+    _chk(d, tuple(y.shape), name='dy')
     srows = 0
     if stat_partial is not None:
         _chk(stat_partial, name='stat_partial')
         if stat_partial.dim() != 3 or stat_partial.shape[0] != 2 or stat_partial.shape[2] != C:
             raise ValueError(f'bn_backward: stat_partial {tuple(stat_partial.shape)} is not (2, rows, {C})')
         srows = stat_partial.shape[1]
+    ws = _bn_ws(M, C, y.device)
     check(lib().bdv_bn_backward(_p(dout), _p(relu_mask if relu else None), _p(y), _p(gamma), _p(save_mean), _p(save_invstd),
-                                _p(d), _p(coef), _p(dgamma), _p(dbeta), float(beta_acc), M, C, int(bool(relu)),
-                                _p(stat_partial), srows, _p(ws), ws.numel(), _stream()), 'bdv_bn_backward')
-    return (coef if reduce_only else d), dgamma, dbeta
+                                _p(d), _p(dgamma), _p(dbeta), float(beta_acc), M, C, int(bool(relu)), _p(stat_partial), srows,
+                                _p(ws), ws.numel(), _stream()), 'bdv_bn_backward')
+    return d, dgamma, dbeta
 
 
 def bn_backward_maxpool(dpool, pool_idx, relu_mask, y, gamma, save_mean, save_invstd):

@@ -73,18 +73,6 @@ typedef struct bdv_conv_affine {
 int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* g, float* bn_partial,
                    const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream);
 
-/* BatchNorm(+ReLU) backward "apply" step fused into wgrad: instead of a materialised dy the wgrad kernel reads
- * the gradient w.r.t. the BN/ReLU output, the ReLU sign mask, the saved conv output and the coefficients written
- * by bdv_bn_backward(fused_coef); it forms dy = A*(dout & mask) - Bc*(y - mean) - Cc in registers while staging
- * its operand tile and also writes it to dy_out (once per element) for the dgrad that follows. */
-typedef struct bdv_bn_bwd_fuse {
-  const float* dout;         /* [N,Ho,Wo,Cout] */
-  const uint32_t* relu_mask; /* 1 bit per element of dout, or NULL (no ReLU) */
-  const float* y;            /* [N,Ho,Wo,Cout] conv output saved by the forward pass */
-  const float* coef;         /* float[4][Cout]: A, Bc, Cc, mean */
-  float* dy_out;             /* [N,Ho,Wo,Cout] */
-} bdv_bn_bwd_fuse;
-
 /* BatchNorm-backward statistics fused into dgrad: dx (the gradient w.r.t. the BN(+ReLU) output of the PREVIOUS conv unit,
  * whose saved conv output is y) is reduced in the dgrad epilogue to partial[0][r][c] = sum(g), partial[1][r][c] =
  * sum(g * xhat) per 128-row tile r (g = dx * mask, xhat = (y - mean) * invstd; rows = bdv_conv_dgrad_stat_rows(g));
@@ -108,8 +96,8 @@ int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const float* add_
 
 /* wgrad: dw[Cout,R,S,Cin] = beta * dw + sum_pixels dy (x) shift(x).  Deterministic split-K:
  * partial slabs go to `workspace`, a second kernel reduces them in fixed order. */
-int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float beta, const bdv_conv_geom* g,
-                   const bdv_bn_bwd_fuse* bn, void* workspace, size_t workspace_bytes, void* stream);
+int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float beta, const bdv_conv_geom* g, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* ---- BatchNorm2d (train + eval), fused with ReLU / residual add --------------------------
  * Replaces UPSTREAM ConvModule.bn (+ .activate, + block `out + identity`) and their autograd.
@@ -140,11 +128,9 @@ int bdv_bn_apply(const float* y, const float* scale, const float* shift, const f
  * dbeta = sum g, dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).  dgamma/dbeta are written as
  * beta_acc*old + new.  The residual-path gradient is g itself; consumers re-derive it from
  * (dout, relu_mask) -- see bdv_conv_dgrad(add_src, add_mask_src) and bdv_relu_bwd. */
-/* dy may be NULL when fused_coef (float[4][C]) is given: then only the reductions run and the conv backward kernels
- * apply  dy = A*g - Bc*(y - mean) - Cc  inside their operand loaders (bdv_bn_bwd_fuse), so dy never touches HBM. */
 /* stat_partial (optional): float[2][stat_rows][C] written by bdv_conv_dgrad(bn_stat); the statistics pass is skipped. */
 int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, const float* y, const float* gamma,
-                    const float* save_mean, const float* save_invstd, float* dy, float* fused_coef, float* dgamma,
+                    const float* save_mean, const float* save_invstd, float* dy, float* dgamma,
                     float* dbeta, float beta_acc, int64_t M, int C, int relu, const float* stat_partial, int stat_rows,
                     void* workspace, size_t workspace_bytes, void* stream);
 /* g = dout * relu_mask (+ add) : masked gradient for an identity path that has no conv behind it */

@@ -176,61 +176,6 @@ def test_fused_bn_statistics(shape, dev):
     assert (rvd.cpu().double() - (0.9 + 0.1 * yc.var(0, unbiased=True))).abs().max() <= 1e-4
 
 
-# BatchNorm(+ReLU) backward fused into wgrad: conv -> BN(train) -> ReLU on the oracle side, autograd gives
-# d(loss)/d(weight), d/d(gamma), d/d(beta) and the gradient at the conv output (dy).
-FUSED_CASES = [
-    (8, 14, 14, 64, 128, 1, 1, 0, 1, 0),      # 64x64 wgrad tiles
-    (16, 6, 6, 256, 128, 1, 1, 0, 8, 32),     # 128x128 tiles, shift, ragged reduction length (576 rows)
-    (2, 9, 9, 128, 128, 3, 1, 1, 1, 0),       # 3x3: 9 N tiles, only the first writes dy (M = 162: ragged)
-    (8, 8, 8, 64, 128, 3, 2, 1, 8, 8),        # stride 2 + shift
-    (8, 7, 7, 256, 512, 3, 1, 1, 1, 0),       # 4 row tiles of dy columns
-]
-
-
-@pytest.mark.parametrize('case', FUSED_CASES)
-@pytest.mark.parametrize('relu', [True, False])
-def test_wgrad_fused_bn_backward(case, relu, dev):
-    from bdvcil_amd import kernels as K
-    N, H, W, Cin, Cout, R, st, pad, T, fold = case
-    x, w = _mk(case, 4)
-    gen = torch.Generator().manual_seed(21)
-    gamma = (torch.rand(Cout, generator=gen) + 0.5).requires_grad_(True)
-    beta = (torch.randn(Cout, generator=gen) * 0.3).requires_grad_(True)
-    w.requires_grad_(True)
-    y = _ref(x, w, st, pad, T, fold)
-    y.retain_grad()
-    o = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
-    if relu:
-        o = F.relu(o)
-    dout = torch.randn(o.shape, generator=gen)
-    o.backward(dout)
-
-    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
-    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
-    wd = w.detach().permute(0, 2, 3, 1).contiguous().to(dev)
-    doutd = dout.permute(0, 2, 3, 1).contiguous().to(dev)
-    yd, part = K.conv_fprop(xd, wd, g, bn_stats=True)
-    mean, invstd, scale, shift = K.bn_train_finalize(part, g.N * g.Ho * g.Wo, gamma.detach().to(dev), beta.detach().to(dev),
-                                                     1e-5, 0.1, None, None)
-    mask = None
-    if relu:
-        _, mask = K.bn_apply(yd, scale, shift, None, True, want_mask=True)
-    coef, dg, db = K.bn_backward(doutd, mask, yd, gamma.detach().to(dev), mean, invstd, relu, reduce_only=True)
-    assert coef.shape == (4, Cout)
-    dy = torch.full_like(yd, float('nan'))
-    dw = K.conv_wgrad(None, xd, g, bn_fuse=(doutd, mask, yd, coef, dy))
-    torch.cuda.synchronize()
-    _close(dg.cpu(), gamma.grad, tol=5e-5)
-    _close(db.cpu(), beta.grad, tol=5e-5)
-    _close(dy.cpu().permute(0, 3, 1, 2), y.grad, tol=5e-5)
-    _close(dw.cpu(), w.grad.permute(0, 2, 3, 1), tol=5e-5)
-    # the separate apply kernel gives the same dy up to rounding of the regrouped coefficients
-    dy2, _, _ = K.bn_backward(doutd, mask, yd, gamma.detach().to(dev), mean, invstd, relu)
-    _close(dy, dy2, tol=1e-5)
-    with pytest.raises(ValueError):
-        K.conv_wgrad(dy2, xd, g, bn_fuse=(doutd, mask, yd, coef, dy))
-
-
 # BatchNorm-backward statistics taken in the dgrad epilogue: dx of this conv is the gradient entering the previous
 # unit's BN(+ReLU); partial[0] / partial[1] summed over the row tiles must equal sum(g) and sum(g * xhat), and
 # bn_backward fed with them must give what the separate statistics pass gives.
