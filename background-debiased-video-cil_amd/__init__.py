@@ -11,6 +11,8 @@ Import as ``bdvcil_amd`` (see ``bdvcil_amd.py`` at the repo root).  Layout:
 * ``frontend``     fused background-mix + normalize
 * ``cil_step``     training-step arithmetic of BaseCIL / ICARLModel + a step engine
 * ``ddp``          bucketed gradient all-reduce over RCCL
+* ``representation``  predict_step / NME classifier / class means / herding
+* ``task_loop``    the CIL task loop (CILTrainer + CILDataModule bookkeeping, same files on disk)
 """
 from . import _lib, kernels  # noqa: F401
 from .registry import (BACKBONES, HEADS, LOSSES, OPTIMIZER_BUILDERS, RECOGNIZERS, Registry, build_backbone,  # noqa: F401
@@ -26,5 +28,6 @@ from .frontend import BackgroundMixFrontEnd  # noqa: F401
 from .cil_step import TrainEngine, base_training_step, icarl_training_step  # noqa: F401
 from .ddp import GradAllReducer, broadcast_parameters  # noqa: F401
 from .representation import Herding, ReprPredictor, class_means_from_repr, nme_classify  # noqa: F401
+from .task_loop import CILTaskLoop, CILWorkDir, RawframeRecords, SyntheticClipLoader, TaskSplits  # noqa: F401
 
 __version__ = '0.1.0'

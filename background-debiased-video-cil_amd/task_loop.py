@@ -468,6 +468,9 @@ class CILTaskLoop:
         scheduler = build_lr_scheduler(optimizer, sch_cfg) if sch_cfg else None
         reducer = None
         if self.world > 1:
+            # DistributedDataParallel is constructed per fit and starts from rank 0's weights and buffers: this is what
+            # makes the freshly initialised classifier rows of ``update_fc`` agree across ranks
+            broadcast_parameters(self.current_model)
             reducer = GradAllReducer(self.current_model)
             optimizer.set_grad_scale(reducer.grad_scale)
         clip = None if self._current_task == 0 else 1.0
