@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _lib = None
 
@@ -86,6 +86,8 @@ SIGNATURES = {
     'bdv_class_means': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'bdv_herding_workspace_bytes': (c_size_t, [c_int, c_int]),
     'bdv_herding_select': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
+    'bdv_randaug_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'bdv_randaug_apply': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'bdv_reduce_workspace_bytes': (c_size_t, []),
     'bdv_kd_mse_fwd': (c_int, [P, P, P, c_int64, P, c_size_t, P]),
     'bdv_kd_mse_bwd': (c_int, [P, P, P, c_float, P, c_int64, P]),

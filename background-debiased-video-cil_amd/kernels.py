@@ -659,3 +659,29 @@ def herding_select(features, num_exemplars, cosine_distance):
     check(lib().bdv_herding_select(_p(features), n, D, m, int(bool(cosine_distance)), _p(cm), _p(idx), _p(dist), _p(ws),
                                    ws.numel(), _stream()), 'bdv_herding_select')
     return cm, idx[:m], dist[:m]
+
+
+# ---- data path: RandAugment on uint8 frames ---------------------------------------------------------------------------
+
+RANDAUG_NUM_OPS = 12
+
+
+def randaug_apply(frames_u8, op_i, op_d, out=None):
+    """One operation slot of RandAugment for a batch of clips.  frames_u8 (B, T, H, W, 3) uint8; op_i (B, 8) int32 and
+    op_d (B, 4) float64 device tables (layout: include/bdvcil_hip.h, bdv_randaug_apply) -> new (B, T, H, W, 3) uint8."""
+    _chk(frames_u8, dtype=torch.uint8, name='frames_u8')
+    if frames_u8.dim() != 5 or frames_u8.shape[-1] != 3:
+        raise ValueError(f'randaug_apply: frames must be (B, T, H, W, 3), got {tuple(frames_u8.shape)}')
+    B, T, H, W, _ = frames_u8.shape
+    _chk(op_i, (B, 8), torch.int32, 'op_i')
+    _chk(op_d, (B, 4), torch.float64, 'op_d')
+    if out is None:
+        out = torch.empty_like(frames_u8)
+    else:
+        _chk(out, frames_u8.shape, torch.uint8, 'out')
+        if out.data_ptr() == frames_u8.data_ptr():
+            raise ValueError('randaug_apply: out must not alias the input')
+    ws = workspace(lib().bdv_randaug_workspace_bytes(B, T, H, W), frames_u8.device, 'randaug')
+    check(lib().bdv_randaug_apply(_p(frames_u8), _p(out), _p(op_i), _p(op_d), B, T, H, W, _p(ws), ws.numel(), _stream()),
+          'bdv_randaug_apply')
+    return out

@@ -241,6 +241,22 @@ int bdv_herding_select(const float* features, int n, int D, int num_exemplars, i
                        float* class_mean, int64_t* indices, float* dist, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* ---- data path: RandAugment on uint8 frames ---------------------
+ * libs/pipelines/rand_augment.py:17-160 as applied by RandAugment._rand_aug (:237-264): ONE operation per clip (the
+ * same for each of its T frames), bit-identical to the Pillow routines the reference calls.  in / out: (B, T, H, W, 3)
+ * uint8 RGB, distinct buffers.  op_i (B, 8) int32 and op_d (B, 4) float64 are device tables, one row per clip:
+ *   op_i[0] = operation: 0 Identity | 1 AutoContrast | 2 Equalize | 3 Solarize (op_d[0] = threshold) |
+ *             4 Posterize (op_i[1] = bits) | 5 Color | 6 Contrast | 7 Brightness | 8 Sharpness (op_d[0] = factor in [0,1]) |
+ *             9 affine, nearest, 16.16 fixed point: ShearX / ShearY / Rotate (op_i[1..6] = FIX(a0) FIX(a1)
+ *               FIX(a2 + a0/2 + a1/2) FIX(a3) FIX(a4) FIX(a5 + a3/2 + a4/2), FIX(v) = floor(v * 65536 + 0.5)) |
+ *            10 affine without cross terms: TranslateX / TranslateY (op_d[0..3] = a0 a2 a4 a5) |
+ *            11 CutoutAbs (op_i[1..4] = x0 y0 x1 y1, inclusive)
+ *   op_i[7] = fill colour 0xRRGGBB for operations 9-11 (FILL_COLOR (124,116,104), rand_augment.py:15).
+ * Three launches per call (histograms, per-frame tables, apply); call once per operation slot (n = 2 in every config). */
+size_t bdv_randaug_workspace_bytes(int B, int T, int H, int W);
+int bdv_randaug_apply(const uint8_t* in, uint8_t* out, const int32_t* op_i, const double* op_d, int B, int T, int H,
+                      int W, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- optimizer: multi-tensor global-norm clip + SGD(momentum, wd) ---------------------------
  * torch.optim.SGD built at libs/cil/cil.py:467 with the groups of libs/models/cil_heads/tsm.py:273-303
  * and PL gradient_clip_val (cil.py:743).  Tables are device arrays, one entry per tensor. */

@@ -1,0 +1,132 @@
+"""RandAugment kernels (csrc/augment.hip) through the C ABI against the numpy oracle and the reference-generated golden
+vectors: bit-exact for every operation of the table, for whole seeded RandAugment calls and at the full working size
+of the pipeline (256 x 340 frames after Resize(-1, 256))."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment_oracle as AO
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'randaug_golden.npz')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def golden():
+    z = np.load(GOLDEN)
+    return z, json.loads(str(z['cases'])), json.loads(str(z['calls']))
+
+
+def _run_rows(frames, rows_i, rows_d, dev):
+    from bdvcil_amd import kernels as K
+    oi = torch.from_numpy(np.array(rows_i, np.int64).astype(np.int32)).to(dev)
+    od = torch.tensor(rows_d, dtype=torch.float64, device=dev)
+    return K.randaug_apply(torch.from_numpy(frames).to(dev), oi, od).cpu().numpy()
+
+
+def test_every_golden_operation_case_in_one_batch(golden, dev):
+    """All 142 reference cases as one batch of 142 single-frame clips (a different operation per clip)."""
+    from bdvcil_amd import augment as A
+    z, cases, _ = golden
+    H, W = z['imgs'].shape[1:3]
+    frames = np.stack([z['imgs'][c['img']] for c in cases])[:, None]                    # (B, 1, H, W, 3)
+    rows = [A.op_row(c['name'], c['val'], c['flip'], tuple(c['loc']), H, W) for c in cases]
+    got = _run_rows(frames, [r[0] for r in rows], [r[1] for r in rows], dev)
+    for i, c in enumerate(cases):
+        assert np.array_equal(got[i, 0], z[f'op{i}']), (i, c)
+
+
+def test_whole_seeded_calls_match_the_reference(golden, dev):
+    from bdvcil_amd import augment as A
+    z, _, calls = golden
+    aug = A.RandAugment(2, 10, 0.75)
+    draws, frames = [], []
+    for c in calls:
+        random.seed(c['seed'])
+        np.random.seed(c['seed'])
+        draws.append(aug.draw(24, 36))
+        frames.append(np.stack([z['imgs'][k] for k in c['imgs']]))
+    x = torch.from_numpy(np.stack(frames)).to(dev)                                       # (40, 2, 24, 36, 3)
+    got = aug.apply_draws(x, draws).cpu().numpy()
+    for b, c in enumerate(calls):
+        assert (draws[b] is not None) == c['randAug']
+        assert np.array_equal(got[b], z[f'call{c["seed"]}']), c
+    # __call__ draws per sample in batch order from the global generators, like B consecutive reference calls
+    random.seed(123)
+    np.random.seed(123)
+    ref_draws = [aug.draw(24, 36) for _ in range(40)]
+    random.seed(123)
+    np.random.seed(123)
+    out, flags = aug(x)
+    assert flags.tolist() == [d is not None for d in ref_draws]
+    assert torch.equal(out, aug.apply_draws(x, ref_draws))
+
+
+@pytest.mark.parametrize('H,W,T', [(256, 340, 8), (37, 53, 3)])
+def test_full_size_batch_against_oracle(H, W, T, dev):
+    """One clip per table entry (plus flipped signs), T frames each, at the pipeline's working size."""
+    from bdvcil_amd import augment as A
+    rng = np.random.default_rng(H * 1000 + W)
+    entries = [(n, lo, hi, f) for n, lo, hi in AO.OP_TABLE for f in ((False, True) if n in ('Rotate', 'ShearX', 'ShearY', 'TranslateX', 'TranslateY') else (False,))]
+    B = len(entries)
+    frames = rng.integers(0, 256, (B, T, H, W, 3), dtype=np.uint8)
+    frames[B // 2:] = (frames[B // 2:].astype(np.int32) * 5 // 8 + 30).astype(np.uint8)     # limited range: autocontrast / equalize act
+    frames[::3, :, : H // 2] = (frames[::3, :, : H // 2] // 16) * 16
+    rows, want = [], np.empty_like(frames)
+    for b, (name, lo, hi, flip) in enumerate(entries):
+        val = (10.0 / 30) * float(hi - lo) + lo
+        loc = (float(rng.uniform(1, W)), float(rng.uniform(1, H)))
+        rows.append(A.op_row(name, val, flip, loc, H, W))
+        for t in range(T):
+            want[b, t] = AO.apply_op(name, frames[b, t], val, flip, loc)
+    got = _run_rows(frames, [r[0] for r in rows], [r[1] for r in rows], dev)
+    for b, e in enumerate(entries):
+        assert np.array_equal(got[b], want[b]), (e, int((got[b] != want[b]).sum()))
+    assert sum(not np.array_equal(got[b], frames[b]) for b in range(B)) >= B - 3            # the operations do act (Identity, full-range AutoContrast stay)
+
+
+def test_edge_values_and_errors(dev):
+    from bdvcil_amd import augment as A
+    from bdvcil_amd import kernels as K
+    from bdvcil_amd._lib import HipExtensionError
+    rng = np.random.default_rng(3)
+    H, W = 19, 23
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    const = np.full((H, W, 3), 200, np.uint8)                        # single occupied bin: autocontrast / equalize = identity
+    two = const.copy()
+    two[:, :3] = 10                                                   # two bins, step = 0 for equalize on a tiny image
+    cases = [('AutoContrast', const, 0, False, (0, 0)), ('Equalize', const, 0, False, (0, 0)), ('Equalize', two, 0, False, (0, 0)),
+             ('AutoContrast', two, 0, False, (0, 0)), ('Solarize', img, 0.0, False, (0, 0)), ('Solarize', img, 256.0, False, (0, 0)),
+             ('Posterize', img, 8, False, (0, 0)), ('Posterize', img, 0.3, False, (0, 0)), ('Rotate', img, 30.0, True, (0, 0)),
+             ('ShearX', img, 0.3, False, (0, 0)), ('ShearY', img, 0.3, True, (0, 0)), ('TranslateX', img, 0.45, True, (0, 0)),
+             ('TranslateY', img, 0.45, False, (0, 0)), ('TranslateX', img, 0.0, False, (0, 0)), ('CutoutAbs', img, 112.0, False, (0.1, 0.1)),
+             ('CutoutAbs', img, 0.0, False, (W - 0.01, H - 0.01)), ('Brightness', img, 0.05, False, (0, 0)), ('Color', img, 0.95, False, (0, 0)),
+             ('Contrast', const, 0.5, False, (0, 0)), ('Sharpness', two, 0.05, False, (0, 0))]
+    frames = np.stack([c[1] for c in cases])[:, None]
+    rows = [A.op_row(c[0], c[2], c[3], c[4], H, W) for c in cases]
+    got = _run_rows(frames, [r[0] for r in rows], [r[1] for r in rows], dev)
+    for i, c in enumerate(cases):
+        assert np.array_equal(got[i, 0], AO.apply_op(c[0], c[1], c[2], c[3], c[4])), (i, c[0], c[2])
+    x = torch.from_numpy(frames).to(dev)
+    oi = torch.zeros(len(cases), 8, dtype=torch.int32, device=dev)
+    od = torch.zeros(len(cases), 4, dtype=torch.float64, device=dev)
+    with pytest.raises(ValueError):
+        K.randaug_apply(x, oi, od, out=x)                             # in place
+    with pytest.raises(ValueError):
+        K.randaug_apply(x[..., :2].contiguous(), oi, od)              # not RGB
+    with pytest.raises(ValueError):
+        K.randaug_apply(x, oi[:-1], od)                               # one row per clip
+    with pytest.raises(RuntimeError):
+        K.randaug_apply(x.cpu(), oi, od)                              # no CPU fallback
+    with pytest.raises(HipExtensionError):
+        K.randaug_apply(x[:, :, :2].contiguous(), oi, od)             # H < 3: no 3x3 neighbourhood
