@@ -8,7 +8,8 @@ Import as ``bdvcil_amd`` (see ``bdvcil_amd.py`` at the repo root).  Layout:
 * ``functional``   autograd glue (block-level Functions)
 * ``registry``, ``recognizer``, ``resnet_tsm``, ``heads``, ``losses``, ``hooks``, ``optim``
                    the reference's mmaction2-style plugin surface (same names / signatures / state_dict keys)
-* ``frontend``     fused background-mix + normalize
+* ``frontend``     fused background-mix + normalize; train front-end = RandAugment -> mix decision -> blend
+* ``augment``      RandAugment for batches of uint8 clips (draws + device tables; pixels in csrc/augment.hip)
 * ``cil_step``     training-step arithmetic of BaseCIL / ICARLModel + a step engine
 * ``ddp``          bucketed gradient all-reduce over RCCL
 * ``representation``  predict_step / NME classifier / class means / herding
@@ -24,7 +25,8 @@ from .recognizer import CILRecognizer2D, Recognizer2D  # noqa: F401
 from .hooks import OutputHook, rgetattr  # noqa: F401
 from .optim import (CILTSMOptimizerConstructor, CILTSMOptimizerConstructorImprovised, FusedSGD, build_lr_scheduler,  # noqa: F401
                     build_optimizer)
-from .frontend import BackgroundMixFrontEnd  # noqa: F401
+from .frontend import BackgroundMixFrontEnd, TrainClipFrontEnd  # noqa: F401
+from .augment import RandAugment  # noqa: F401
 from .cil_step import TrainEngine, base_training_step, icarl_training_step  # noqa: F401
 from .ddp import GradAllReducer, broadcast_parameters  # noqa: F401
 from .representation import Herding, ReprPredictor, class_means_from_repr, nme_classify  # noqa: F401

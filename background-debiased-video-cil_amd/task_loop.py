@@ -250,16 +250,19 @@ class SyntheticClipLoader:
     """Deterministic stand-in for the decode pipeline with the reference's collated batch layout.
 
     Every video is a fixed uint8 clip derived from a CRC of its ``frame_dir`` plus a class-dependent low-frequency
-    pattern (so a few epochs separate the classes); training batches go through the fused background-mix + normalize
-    front-end with a per-sample mix decision of probability ``1 - randAug_prob`` (comix_loader.py:110-116), all other
-    phases through normalize only.  Keys: ``imgs`` (B, T, 3, H, W), ``label`` (B, 1) and the meta data
+    pattern (so a few epochs separate the classes); training batches go through ``TrainClipFrontEnd`` (RandAugment with
+    probability ``randAug_prob``, background mix for the samples it skipped, comix_loader.py:105-116), all other phases
+    through normalize only.  Keys: ``imgs`` (B, T, 3, H, W), ``label`` (B, 1) and the meta data
     ``frame_dir`` / ``total_frames`` / ``clip_len`` / ``num_clips`` / ``frame_inds`` that ``predict_step`` passes through."""
 
     def __init__(self, device, num_segments: int = 8, size: int = 64, randAug_prob: float = 0.75, alpha: float = 0.5, seed: int = 0):
-        from .frontend import BackgroundMixFrontEnd
+        from .augment import RandAugment
+        from .frontend import BackgroundMixFrontEnd, TrainClipFrontEnd
         self.device = torch.device(device)
-        self.T, self.size, self.p_mix, self.seed = num_segments, size, 1.0 - randAug_prob, seed
+        self.T, self.size, self.seed = num_segments, size, seed
         self.front = BackgroundMixFrontEnd(alpha=alpha)
+        # the train pipeline of the configs: RandAugment(n=2, m=10, prob), background mix when it did not fire
+        self.train_front = TrainClipFrontEnd(RandAugment(2, 10, randAug_prob), alpha=alpha, with_randAug=True)
         self._draws = 0
 
     def _frames(self, info: dict) -> np.ndarray:
@@ -279,14 +282,15 @@ class SyntheticClipLoader:
         if phase == 'train':
             g = torch.Generator().manual_seed(self.seed * 7919 + self._draws)
             self._draws += 1
-            mix = (torch.rand(B, generator=g) < self.p_mix).to(self.device)
             bg = torch.randint(0, 256, (B, self.size, self.size, 3), generator=g, dtype=torch.uint8).to(self.device)
-            imgs = self.front.as_nchw(frames, bg, mix)
+            imgs, rand_flags, _ = self.train_front(frames, bg, as_nchw=True)
         else:
-            imgs = self.front.as_nchw(frames)
+            imgs, rand_flags = self.front.as_nchw(frames), None
         tf = torch.tensor([v['total_frames'] for v in video_infos], dtype=torch.int64)
         dev = self.device                       # Lightning moves every tensor of the batch to the device
+        extra = {} if rand_flags is None else {'randAug': rand_flags}       # Collect(keys=['imgs', 'label', 'randAug'])
         return {
+            **extra,
             'imgs': imgs,
             'label': torch.tensor([[v['label']] for v in video_infos], dtype=torch.int64, device=self.device),
             'frame_dir': [v['frame_dir'] for v in video_infos],

@@ -130,3 +130,42 @@ def test_edge_values_and_errors(dev):
         K.randaug_apply(x.cpu(), oi, od)                              # no CPU fallback
     with pytest.raises(HipExtensionError):
         K.randaug_apply(x[:, :, :2].contiguous(), oi, od)             # H < 3: no 3x3 neighbourhood
+
+
+def test_train_front_end_randaug_then_background_mix(dev):
+    """TrainClipFrontEnd = RandAugment, then background mix for exactly the samples RandAugment skipped
+    (comix_loader.py:105-116), against the two oracles chained sample by sample with the same generator state."""
+    import bdvcil_amd as bd
+    from oracle import tsm_oracle as O
+    rng = np.random.default_rng(11)
+    B, T, H, W = 12, 3, 40, 56
+    frames = rng.integers(0, 256, (B, T, H, W, 3), dtype=np.uint8)
+    bg = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    front = bd.TrainClipFrontEnd(bd.RandAugment(2, 10, 0.75), alpha=0.5, with_randAug=True)
+    random.seed(5)
+    np.random.seed(5)
+    imgs, rand_flags, mixed = front(torch.from_numpy(frames).to(dev), torch.from_numpy(bg).to(dev), as_nchw=True)
+    random.seed(5)
+    np.random.seed(5)
+    want_frames, want_flags = [], []
+    for b in range(B):
+        fr, flag, _ = AO.rand_augment([frames[b, t] for t in range(T)], 2, 10, 0.75)
+        want_frames.append(np.stack(fr))
+        want_flags.append(flag)
+    assert rand_flags.tolist() == want_flags and mixed.tolist() == [not f for f in want_flags]
+    assert 0 < sum(want_flags) < B
+    ref = O.bgmix_normalize(torch.from_numpy(np.stack(want_frames)), torch.from_numpy(bg), ~torch.tensor(want_flags), 0.5)
+    assert torch.equal(imgs.cpu(), ref)
+    # the NHWC4 form that feeds the stem holds the same values
+    random.seed(5)
+    np.random.seed(5)
+    packed, _, _ = front(torch.from_numpy(frames).to(dev), torch.from_numpy(bg).to(dev))
+    assert torch.equal(packed.data.cpu()[..., :3].reshape(B, T, H, W, 3).permute(0, 1, 4, 2, 3), ref)
+    # without RandAugment in the pipeline the mix is a per-sample coin of probability `prob`
+    plain = bd.TrainClipFrontEnd(None, alpha=0.5, prob=0.25, with_randAug=False)
+    random.seed(9)
+    _, rf, mx = plain(torch.from_numpy(frames).to(dev), torch.from_numpy(bg).to(dev), as_nchw=True)
+    random.seed(9)
+    assert mx.tolist() == [random.random() < 0.25 for _ in range(B)] and not rf.any()
+    with pytest.raises(ValueError):
+        bd.TrainClipFrontEnd(None, with_randAug=True)(torch.from_numpy(frames).to(dev), torch.from_numpy(bg).to(dev))
