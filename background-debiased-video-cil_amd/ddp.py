@@ -8,7 +8,8 @@ gradient has been accumulated, overlapping the remaining backward.  The mean is 
 step (``FusedSGD.set_grad_scale(1/world)``), so no extra pass over the gradients.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): RCCL's ring moves 2*(R-1)/R of the payload over one link per
-hop, so few, large buckets (default 4 x ~24 MB for the 94.9 MB R50 payload) beat many small ones.
+hop, so few, large buckets (default 4 x ~24 MB for the 94.9 MB R50 payload) beat many small ones; the last one is split
+so that only <= 2 MB (stem + first block) are reduced after backward has ended.
 Deliberate deviation from DDP defaults: BN buffers are not broadcast every iteration (per-GPU statistics, no
 SyncBN in the reference).
 """
@@ -56,22 +57,34 @@ class _Bucket:
 
 
 class GradAllReducer:
-    def __init__(self, module: torch.nn.Module, bucket_cap_mb: float = 25.0, process_group=None):
+    def __init__(self, module: torch.nn.Module, bucket_cap_mb: float = 25.0, process_group=None, tail_cap_mb: float = 2.0):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in module.parameters() if p.requires_grad]
         params.reverse()
         cap = int(bucket_cap_mb * 1024 * 1024 / 4)
-        self.buckets: List[_Bucket] = []
+        groups: List[List[torch.nn.Parameter]] = []
         cur, n = [], 0
         for p in params:
             cur.append(p)
             n += p.numel()
             if n >= cap:
-                self.buckets.append(_Bucket(cur))
+                groups.append(cur)
                 cur, n = [], 0
         if cur:
-            self.buckets.append(_Bucket(cur))
+            groups.append(cur)
+        # The last bucket becomes ready only when backward has finished (it holds the stem), so its all-reduce is the one
+        # collective nothing can hide: keep it small by splitting the earliest layers (<= tail_cap_mb) off into their own
+        # bucket; the rest of that bucket then overlaps with the backward of those layers.
+        tail_cap = int(tail_cap_mb * 1024 * 1024 / 4)
+        if groups and tail_cap > 0 and sum(p.numel() for p in groups[-1]) > tail_cap and len(groups[-1]) > 1:
+            last, tail, n = groups[-1], [], 0
+            while len(last) > 1 and n + last[-1].numel() <= tail_cap:
+                n += last[-1].numel()
+                tail.insert(0, last.pop())
+            if tail:
+                groups.append(tail)
+        self.buckets: List[_Bucket] = [_Bucket(g) for g in groups]
         self._index = {}
         self._handles = []
         for bi, b in enumerate(self.buckets):

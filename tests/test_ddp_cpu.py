@@ -83,3 +83,28 @@ def test_gloo_world2_allreduce_matches_full_batch(bucket_mb):
     loss.backward()
     for got, p in zip(res[0][1], model.parameters()):
         assert torch.allclose(torch.from_numpy(got), p.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_tail_bucket_split():
+    """The bucket that closes last (earliest layers) is split so that only a small tail is reduced after backward."""
+    import bdvcil_amd as bd
+    torch.manual_seed(0)
+    layers = [nn.Linear(64, 64, bias=False) for _ in range(10)]                   # 16 KB each, registration order = forward order
+    model = nn.Sequential(*layers)
+    r = bd.GradAllReducer(model, bucket_cap_mb=0.0625, tail_cap_mb=0.03125)       # 64 KB buckets, 32 KB tail
+    sizes = [[p.numel() * 4 for p in b.params] for b in r.buckets]
+    assert [sum(s) for s in sizes] == [65536, 65536, 32768]
+    r.remove()
+    r = bd.GradAllReducer(model, bucket_cap_mb=0.0625, tail_cap_mb=0.0234375)     # 24 KB tail: one 16 KB tensor fits
+    assert [sum(p.numel() * 4 for p in b.params) for b in r.buckets] == [65536, 65536, 16384, 16384]
+    # order: the tail bucket holds the FIRST layers of the model (their gradients arrive last)
+    assert r.buckets[-1].params[0] is layers[0].weight
+    covered = [p for b in r.buckets for p in b.params]
+    assert len(covered) == 10 and len({id(p) for p in covered}) == 10
+    r.remove()
+    r = bd.GradAllReducer(model, bucket_cap_mb=0.0625, tail_cap_mb=0)             # disabled
+    assert [sum(p.numel() * 4 for p in b.params) for b in r.buckets] == [65536, 65536, 32768]
+    r.remove()
+    r = bd.GradAllReducer(model, bucket_cap_mb=25.0, tail_cap_mb=0.001)           # nothing fits the tail: unchanged
+    assert len(r.buckets) == 1
+    r.remove()
