@@ -25,7 +25,7 @@ from .recognizer import CILRecognizer2D, Recognizer2D  # noqa: F401
 from .hooks import OutputHook, rgetattr  # noqa: F401
 from .optim import (CILTSMOptimizerConstructor, CILTSMOptimizerConstructorImprovised, FusedSGD, build_lr_scheduler,  # noqa: F401
                     build_optimizer)
-from .frontend import BackgroundMixFrontEnd, TrainClipFrontEnd  # noqa: F401
+from .frontend import BackgroundMixFrontEnd, CropFrontEnd, TrainClipFrontEnd, crop_offsets  # noqa: F401
 from .augment import RandAugment  # noqa: F401
 from .cil_step import TrainEngine, base_training_step, icarl_training_step  # noqa: F401
 from .ddp import GradAllReducer, broadcast_parameters  # noqa: F401

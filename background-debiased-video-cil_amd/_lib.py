@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lib = None
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     'bdv_avgpool_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'bdv_avgpool_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'bdv_bgmix_normalize_u8': (c_int, [P, P, P, c_float, _F3, _F3, _F3, P, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_crop_normalize_u8': (c_int, [P, P, c_int, c_int, c_int, _F3, _F3, P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_lsc_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_lsc_bwd': (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, P]),
     'bdv_linear_fwd': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),

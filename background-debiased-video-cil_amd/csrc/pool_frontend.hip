@@ -207,6 +207,42 @@ __global__ __launch_bounds__(256) void bgmix_normalize_kernel(const uint8_t* __r
   }
 }
 
+// Test-time front-end: fixed crops (+ horizontal flips) of every frame, normalised, in the order the crop transforms
+// emit them (crop-major, then the T frames).  One thread = one output pixel of one (b, crop), looping over T.
+struct CropTable {
+  int n;
+  int x[BDV_MAX_CROPS], y[BDV_MAX_CROPS], flip[BDV_MAX_CROPS];
+};
+
+__global__ __launch_bounds__(256) void crop_normalize_kernel(const uint8_t* __restrict__ frames, CropTable ct, NormParams np,
+                                                              float4* __restrict__ out_nhwc4, float* __restrict__ out_nchw,
+                                                              int B, int T, int H, int W, int ch, int cw) {
+  const int chw = ch * cw;
+  const int64_t total = (int64_t)B * ct.n * chw;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int p = (int)(i % chw);
+    const int bc = (int)(i / chw);
+    const int b = bc / ct.n, k = bc - b * ct.n;
+    const int oy = p / cw, ox = p - oy * cw;
+    const int sy = ct.y[k] + oy, sx = ct.x[k] + (ct.flip[k] ? cw - 1 - ox : ox);
+    for (int t = 0; t < T; ++t) {
+      const uint8_t* q = frames + ((((int64_t)b * T + t) * H + sy) * W + sx) * 3;
+      float v[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = __fmul_rn(__fsub_rn((float)q[c], np.mean[c]), np.inv_std[c]);
+      const int64_t f = ((int64_t)b * ct.n + k) * T + t;
+      if (out_nhwc4 != nullptr) out_nhwc4[f * chw + p] = make_float4(v[0], v[1], v[2], 0.f);
+      if (out_nchw != nullptr) {
+        float* o = out_nchw + f * 3 * chw + p;
+        o[0] = v[0];
+        o[chw] = v[1];
+        o[2 * (int64_t)chw] = v[2];
+      }
+    }
+  }
+}
+
 int ew_grid(int64_t n) {
   int64_t b = (n + 255) / 256;
   if (b > 8192) b = 8192;
@@ -282,6 +318,38 @@ extern "C" int bdv_avgpool_bwd(const float* dout, float* dx, int N, int HW, int 
   hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout, (float4*)dx,
                      N, HW, C / 4);
   BDV_LAUNCH_CHECK("bdv_avgpool_bwd");
+  return BDV_OK;
+}
+
+extern "C" int bdv_crop_normalize_u8(const uint8_t* frames, const int32_t* crops, int ncrops, int crop_h, int crop_w,
+                                     const float mean[3], const float inv_std[3], float* out_nhwc4, float* out_nchw, int B,
+                                     int T, int H, int W, void* stream) {
+  BDV_REQUIRE(frames && crops && mean && inv_std, "bdv_crop_normalize_u8: null pointer");
+  BDV_REQUIRE(out_nhwc4 || out_nchw, "bdv_crop_normalize_u8: no output requested");
+  BDV_REQUIRE(ncrops > 0 && ncrops <= BDV_MAX_CROPS, "bdv_crop_normalize_u8: %d crops (1..%d supported)", ncrops, BDV_MAX_CROPS);
+  BDV_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && crop_h > 0 && crop_w > 0 && crop_h <= H && crop_w <= W,
+              "bdv_crop_normalize_u8: bad shape %dx%d crop of %dx%d", crop_h, crop_w, H, W);
+  BDV_REQUIRE(out_nhwc4 == nullptr || bdv_aligned16(out_nhwc4), "bdv_crop_normalize_u8: alignment");
+  CropTable ct;
+  ct.n = ncrops;
+  for (int k = 0; k < ncrops; ++k) {
+    ct.x[k] = crops[3 * k];
+    ct.y[k] = crops[3 * k + 1];
+    ct.flip[k] = crops[3 * k + 2] != 0;
+    BDV_REQUIRE(ct.x[k] >= 0 && ct.y[k] >= 0 && ct.x[k] + crop_w <= W && ct.y[k] + crop_h <= H,
+                "bdv_crop_normalize_u8: crop %d at (%d, %d) leaves the %dx%d frame", k, ct.x[k], ct.y[k], H, W);
+  }
+  NormParams np;
+  for (int c = 0; c < 3; ++c) {
+    np.mean[c] = mean[c];
+    np.std[c] = 0.f;
+    np.inv_std[c] = inv_std[c];
+  }
+  np.alpha = 0.f;
+  const int64_t total = (int64_t)B * ncrops * crop_h * crop_w;
+  hipLaunchKernelGGL(crop_normalize_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, frames, ct, np,
+                     (float4*)out_nhwc4, out_nchw, B, T, H, W, crop_h, crop_w);
+  BDV_LAUNCH_CHECK("bdv_crop_normalize_u8");
   return BDV_OK;
 }
 

@@ -67,3 +67,55 @@ class TrainClipFrontEnd:
             frames_u8, bg_u8 = self.crop_resize(frames_u8, bg_u8)
         out = self.mix.as_nchw(frames_u8, bg_u8, mixed) if as_nchw else self.mix(frames_u8, bg_u8, mixed)
         return out, rand_flags, mixed
+
+
+def crop_offsets(kind: str, img_h: int, img_w: int, crop_h: int, crop_w: int):
+    """``(x_offset, y_offset, flip)`` of the fixed test-time crop transforms, in emission order.
+
+    ``FiveCrop``: the reference's own transform (libs/pipelines/five_crops.py:81-92): corners on a quarter-step grid, then
+    the centre.  ``TenCrop`` (UPSTREAM, the class FiveCrop was derived from; :95,:98 keep its flip lines as comments): every
+    crop is followed by its horizontal flip.  ``ThreeCrop`` / ``CenterCrop``: UPSTREAM mmaction2 0.x semantics."""
+    if crop_h > img_h or crop_w > img_w:
+        raise ValueError(f'crop {crop_h}x{crop_w} larger than the {img_h}x{img_w} frame')
+    if kind in ('FiveCrop', 'TenCrop'):
+        w_step, h_step = (img_w - crop_w) // 4, (img_h - crop_h) // 4
+        offs = [(0, 0), (4 * w_step, 0), (0, 4 * h_step), (4 * w_step, 4 * h_step), (2 * w_step, 2 * h_step)]
+        if kind == 'FiveCrop':
+            return [(x, y, 0) for x, y in offs]
+        return [(x, y, f) for x, y in offs for f in (0, 1)]
+    if kind == 'ThreeCrop':
+        if crop_h == img_h:
+            w_step = (img_w - crop_w) // 2
+            return [(0, 0, 0), (2 * w_step, 0, 0), (w_step, 0, 0)]
+        if crop_w == img_w:
+            h_step = (img_h - crop_h) // 2
+            return [(0, 0, 0), (0, 2 * h_step, 0), (0, h_step, 0)]
+        raise ValueError('ThreeCrop needs the crop to span the full height or width of the frame')
+    if kind == 'CenterCrop':
+        return [((img_w - crop_w) // 2, (img_h - crop_h) // 2, 0)]
+    raise KeyError(f'unknown crop transform {kind!r}')
+
+
+class CropFrontEnd:
+    """Device side of the val / test pipelines after decode + Resize: ``CenterCrop`` / ``ThreeCrop`` / ``FiveCrop`` /
+    ``TenCrop`` and ``Normalize`` in one pass.  uint8 frames (B,T,H,W,3) -> the (B, crops*T, ...) clip batch that
+    ``FormatShape('NCHW')`` + collate produce (crop-major), as ``Nhwc4Frames`` for the stem or as an NCHW tensor."""
+
+    def __init__(self, kind: str = 'TenCrop', crop_size=256, mean=IMG_MEAN, std=IMG_STD):
+        self.kind = kind
+        self.crop_w, self.crop_h = (crop_size, crop_size) if isinstance(crop_size, int) else tuple(crop_size)   # (w, h) as mmaction
+        self.mean, self.std = tuple(mean), tuple(std)
+        crop_offsets(kind, self.crop_h, self.crop_w, self.crop_h, self.crop_w)      # validates `kind` early
+
+    def _run(self, frames_u8, nhwc4: bool):
+        B, T, H, W, _ = frames_u8.shape
+        crops = crop_offsets(self.kind, H, W, self.crop_h, self.crop_w)
+        o4, oc = K.crop_normalize_u8(frames_u8, crops, self.crop_h, self.crop_w, self.mean, self.std, nhwc4, not nhwc4)
+        return (o4, oc, B, len(crops) * T)
+
+    def __call__(self, frames_u8: torch.Tensor) -> Nhwc4Frames:
+        o4, _, B, n = self._run(frames_u8, True)
+        return Nhwc4Frames(o4, B, n)
+
+    def as_nchw(self, frames_u8: torch.Tensor) -> torch.Tensor:
+        return self._run(frames_u8, False)[1]

@@ -387,6 +387,26 @@ def bgmix_normalize_u8(frames, bg, mix, alpha, mean, std, want_nhwc4=True, want_
     return o4, oc
 
 
+def crop_normalize_u8(frames, crops, crop_h, crop_w, mean, std, want_nhwc4=True, want_nchw=False):
+    """frames (B,T,H,W,3) u8; crops = [(x_offset, y_offset, flip), ...] -> (o4 (B*n*T, ch, cw, 4) | None,
+    oc (B, n*T, 3, ch, cw) | None), crop-major frame order."""
+    _chk(frames, dtype=torch.uint8, name='frames')
+    if frames.dim() != 5 or frames.shape[-1] != 3:
+        raise ValueError('frames must be (B,T,H,W,3)')
+    B, T, H, W, _ = frames.shape
+    n = len(crops)
+    table = (ctypes.c_int32 * (3 * n))(*[int(v) for c in crops for v in c])
+    f3 = ctypes.c_float * 3
+    m = torch.tensor(list(mean), dtype=torch.float32)
+    inv = 1.0 / torch.tensor(list(std), dtype=torch.float32)      # fp32 reciprocal, as in bgmix_normalize_u8
+    o4 = torch.empty((B * n * T, crop_h, crop_w, 4), dtype=torch.float32, device=frames.device) if want_nhwc4 else None
+    oc = torch.empty((B, n * T, 3, crop_h, crop_w), dtype=torch.float32, device=frames.device) if want_nchw else None
+    check(lib().bdv_crop_normalize_u8(_p(frames), ctypes.cast(table, ctypes.c_void_p), n, int(crop_h), int(crop_w),
+                                      f3(*m.tolist()), f3(*inv.tolist()), _p(o4), _p(oc), B, T, H, W, _stream()),
+          'bdv_crop_normalize_u8')
+    return o4, oc
+
+
 # ---------------------------------------------------------------------------------------------
 # heads / losses
 # ---------------------------------------------------------------------------------------------

@@ -34,6 +34,10 @@ class Nhwc4Frames:
         n, h, w, _ = self.data.shape
         return (self.batches, self.num_segments, 3, h, w)
 
+    def size(self, dim=None):
+        """Like ``Tensor.size`` of the (B, T, 3, H, W) batch this stands for (cil.py reads ``imgs.size(0)``)."""
+        return self.shape if dim is None else self.shape[dim]
+
 
 def _channels_last_(conv: nn.Conv2d):
     conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)

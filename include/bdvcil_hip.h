@@ -170,6 +170,16 @@ int bdv_avgpool_bwd(const float* dout, float* dx, int N, int HW, int C, void* st
 int bdv_bgmix_normalize_u8(const uint8_t* frames, const uint8_t* bg, const uint8_t* mix, float alpha,
                            const float mean[3], const float std[3], const float inv_std[3],
                            float* out_nhwc4, float* out_nchw, int B, int T, int H, int W, void* stream);
+/* Test-time crops + normalize (val/test pipelines, configs/...bgmix_plus_randAug.py:140-171): CenterCrop / ThreeCrop /
+ * TenCrop as emitted by the crop transforms (the reference's own libs/pipelines/five_crops.py:77-100 shows the offset
+ * rule and the crop-major order; TenCrop adds the horizontally flipped copy of each crop right after it).
+ * frames (B,T,H,W,3) uint8; crops = ncrops x (x_offset, y_offset, flip) HOST table, ncrops <= BDV_MAX_CROPS;
+ * out_nhwc4 (B*ncrops*T, crop_h, crop_w, 4) and/or out_nchw (B, ncrops*T, 3, crop_h, crop_w): frame (b, k, t) is
+ * frame t of sample b cropped by entry k, values (x-mean)*inv_std. */
+#define BDV_MAX_CROPS 12
+int bdv_crop_normalize_u8(const uint8_t* frames, const int32_t* crops, int ncrops, int crop_h, int crop_w,
+                          const float mean[3], const float inv_std[3], float* out_nhwc4, float* out_nchw, int B, int T,
+                          int H, int W, void* stream);
 
 /* ---- classifier heads ---------------------------------------------------------------------- */
 /* libs/models/cil_heads/cosine_linear.py:27-43 (LSC): sim[n,k] = sum_p softmax_p(c)[p]*c[p],

@@ -258,3 +258,36 @@ def rand_augment(frames, n, m, prob):
         val = (float(m) / 30) * float(maxval - minval) + minval
         frames = [apply_op(name, f, val, flip_sign, (x0, y0)) for f in frames]
     return frames, True, [o[0] for o in ops]
+
+
+# ---- fixed test-time crops ----------------------------------------------------------------------------------------------
+
+def crop_frames(frames, kind, crop_size):
+    """FiveCrop as the reference ships it (libs/pipelines/five_crops.py:77-100): quarter-step corner offsets then the
+    centre, each crop applied to all frames before the next.  TenCrop = the class it was derived from: the commented
+    lines :95 and :98 put the horizontally flipped copies right after each crop.  ThreeCrop / CenterCrop: mmaction2 0.x
+    (UPSTREAM, not in the reference tree).  frames: list of (H, W, 3) arrays -> list of (crop_h, crop_w, 3) arrays."""
+    crop_w, crop_h = (crop_size, crop_size) if isinstance(crop_size, int) else crop_size
+    img_h, img_w = frames[0].shape[:2]
+    if kind in ('FiveCrop', 'TenCrop'):
+        w_step, h_step = (img_w - crop_w) // 4, (img_h - crop_h) // 4
+        offsets = [(0, 0), (4 * w_step, 0), (0, 4 * h_step), (4 * w_step, 4 * h_step), (2 * w_step, 2 * h_step)]
+    elif kind == 'ThreeCrop':
+        if crop_h == img_h:
+            w_step = (img_w - crop_w) // 2
+            offsets = [(0, 0), (2 * w_step, 0), (w_step, 0)]
+        else:
+            assert crop_w == img_w
+            h_step = (img_h - crop_h) // 2
+            offsets = [(0, 0), (0, 2 * h_step), (0, h_step)]
+    elif kind == 'CenterCrop':
+        offsets = [((img_w - crop_w) // 2, (img_h - crop_h) // 2)]
+    else:
+        raise KeyError(kind)
+    out = []
+    for x, y in offsets:
+        crop = [f[y:y + crop_h, x:x + crop_w] for f in frames]
+        out.extend(crop)
+        if kind == 'TenCrop':
+            out.extend([np.flip(c, axis=1).copy() for c in crop])
+    return out

@@ -112,3 +112,31 @@ def test_host_draws_and_rows_mirror_the_reference(golden):
     assert len(rows) == 2 and rows[0][0].shape == (2, 8) and rows[0][0].dtype.is_floating_point is False
     assert rows[0][0][:, 0].tolist() == [A.IDENTITY, A.SOLARIZE] and rows[1][0][:, 0].tolist() == [A.IDENTITY, A.EQUALIZE]
     assert abs(float(rows[0][1][1, 0]) - 256 / 3) < 1e-12
+
+
+def test_crop_oracle_matches_reference_fivecrop_golden():
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'crops_golden.npz'))
+    from bdvcil_amd import crop_offsets
+    for i in range(int(z['n'])):
+        frames, crop = list(z[f'in{i}']), tuple(int(v) for v in z[f'crop{i}'])
+        got = np.stack(AO.crop_frames(frames, 'FiveCrop', crop))
+        assert np.array_equal(got, z[f'out{i}'])
+        # TenCrop = the same crops, each followed by its mirror image
+        ten = np.stack(AO.crop_frames(frames, 'TenCrop', crop))
+        T = len(frames)
+        for k in range(5):
+            assert np.array_equal(ten[2 * k * T:(2 * k + 1) * T], got[k * T:(k + 1) * T])
+            assert np.array_equal(ten[(2 * k + 1) * T:(2 * k + 2) * T], got[k * T:(k + 1) * T][:, :, ::-1])
+        # the product's offset table is the oracle's
+        H, W = frames[0].shape[:2]
+        offs = crop_offsets('TenCrop', H, W, crop[1], crop[0])
+        assert len(offs) == 10 and [o[2] for o in offs] == [0, 1] * 5
+        for k, (x, y, f) in enumerate(crop_offsets('FiveCrop', H, W, crop[1], crop[0])):
+            assert np.array_equal(frames[0][y:y + crop[1], x:x + crop[0]], got[k * T]) and f == 0
+    assert crop_offsets('CenterCrop', 256, 340, 224, 224) == [(58, 16, 0)]
+    assert crop_offsets('ThreeCrop', 256, 340, 256, 256) == [(0, 0, 0), (84, 0, 0), (42, 0, 0)]
+    assert crop_offsets('TenCrop', 256, 340, 256, 256)[:4] == [(0, 0, 0), (0, 0, 1), (84, 0, 0), (84, 0, 1)]
+    with pytest.raises(KeyError):
+        crop_offsets('SixCrop', 10, 10, 5, 5)
+    with pytest.raises(ValueError):
+        crop_offsets('CenterCrop', 10, 10, 11, 5)

@@ -169,3 +169,64 @@ def test_train_front_end_randaug_then_background_mix(dev):
     assert mx.tolist() == [random.random() < 0.25 for _ in range(B)] and not rf.any()
     with pytest.raises(ValueError):
         bd.TrainClipFrontEnd(None, with_randAug=True)(torch.from_numpy(frames).to(dev), torch.from_numpy(bg).to(dev))
+
+
+@pytest.mark.parametrize('kind,H,W,crop', [('TenCrop', 256, 340, 256), ('ThreeCrop', 256, 340, 256), ('CenterCrop', 256, 340, 224),
+                                            ('FiveCrop', 29, 41, (20, 16)), ('TenCrop', 40, 40, 33)])
+def test_crop_front_end(kind, H, W, crop, dev):
+    """Crops (+ flips) + Normalize in one pass against numpy slicing and the oracle's normalisation, bit-exact, in both
+    output layouts and in the crop-major frame order FormatShape produces."""
+    import bdvcil_amd as bd
+    from oracle import tsm_oracle as O
+    rng = np.random.default_rng(H + W)
+    B, T = 2, 8 if H > 100 else 3
+    frames = rng.integers(0, 256, (B, T, H, W, 3), dtype=np.uint8)
+    front = bd.CropFrontEnd(kind, crop)
+    want = np.stack([np.stack(AO.crop_frames(list(frames[b]), kind, crop)) for b in range(B)])        # (B, n*T, ch, cw, 3)
+    n = want.shape[1] // T
+    ref = O.bgmix_normalize(torch.from_numpy(want), torch.zeros((B,) + want.shape[2:], dtype=torch.uint8),
+                            torch.zeros(B, dtype=torch.bool), 0.5)                                  # (B, n*T, 3, ch, cw), no mix
+    x = torch.from_numpy(frames).to(dev)
+    assert torch.equal(front.as_nchw(x).cpu(), ref)
+    packed = front(x)
+    assert packed.batches == B and packed.num_segments == n * T and tuple(packed.shape) == tuple(ref.shape)
+    assert torch.equal(packed.data.cpu()[..., :3].reshape(B, n * T, *ref.shape[-2:], 3).permute(0, 1, 4, 2, 3), ref)
+    assert float(packed.data[..., 3].abs().max()) == 0.0
+
+
+def test_crop_front_end_feeds_predict_step(dev):
+    """TenCrop clips from the crop front-end through predict_step give the same scores / representations as the same
+    crops handed over as a float (B, 10*T, 3, h, w) tensor."""
+    import bdvcil_amd as bd
+    from test_task_loop_gpu import _model_cfg
+    torch.manual_seed(3)
+    model = bd.build_model(_model_cfg(4)).to(dev).eval()
+    rng = np.random.default_rng(5)
+    frames = torch.from_numpy(rng.integers(0, 256, (2, 8, 40, 52, 3), dtype=np.uint8)).to(dev)
+    front = bd.CropFrontEnd('TenCrop', 32)
+    pred = bd.ReprPredictor(model)
+    a = pred.predict_step({'imgs': front(frames), 'label': torch.zeros(2, 1, dtype=torch.long, device=dev)})
+    b = pred.predict_step({'imgs': front.as_nchw(frames), 'label': torch.zeros(2, 1, dtype=torch.long, device=dev)})
+    pred.close()
+    assert a['repr_'].shape == (2, 10, 512) and a['cls_score'].shape == (2, 4)
+    assert torch.equal(a['cls_score'], b['cls_score']) and torch.equal(a['repr_'], b['repr_'])
+
+
+def test_crop_front_end_errors(dev):
+    import bdvcil_amd as bd
+    from bdvcil_amd import kernels as K
+    from bdvcil_amd._lib import HipExtensionError
+    x = torch.zeros(1, 2, 20, 30, 3, dtype=torch.uint8, device=dev)
+    with pytest.raises(ValueError):
+        bd.CropFrontEnd('CenterCrop', 31)(x)
+    with pytest.raises(KeyError):
+        bd.CropFrontEnd('NoCrop', 8)
+    with pytest.raises(HipExtensionError):
+        K.crop_normalize_u8(x, [(25, 0, 0)], 8, 8, O_MEAN, O_STD)                  # leaves the frame
+    with pytest.raises(HipExtensionError):
+        K.crop_normalize_u8(x, [(0, 0, 0)] * 13, 8, 8, O_MEAN, O_STD)              # more than BDV_MAX_CROPS
+    with pytest.raises(RuntimeError):
+        K.crop_normalize_u8(x.cpu(), [(0, 0, 0)], 8, 8, O_MEAN, O_STD)
+
+
+O_MEAN, O_STD = (123.675, 116.28, 103.53), (58.395, 57.12, 57.375)
