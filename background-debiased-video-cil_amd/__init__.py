@@ -27,7 +27,8 @@ from .optim import (CILTSMOptimizerConstructor, CILTSMOptimizerConstructorImprov
                     build_optimizer)
 from .frontend import BackgroundMixFrontEnd, CropFrontEnd, TrainClipFrontEnd, crop_offsets  # noqa: F401
 from .augment import RandAugment  # noqa: F401
-from .cil_step import TrainEngine, base_training_step, icarl_training_step  # noqa: F401
+from .cil_step import (TrainEngine, base_training_step, icarl_training_step, icarl_video_mix_training_step,  # noqa: F401
+                       tubemix_draw)
 from .ddp import GradAllReducer, broadcast_parameters  # noqa: F401
 from .representation import Herding, ReprPredictor, class_means_from_repr, nme_classify  # noqa: F401
 from .task_loop import CILTaskLoop, CILWorkDir, RawframeRecords, SyntheticClipLoader, TaskSplits  # noqa: F401

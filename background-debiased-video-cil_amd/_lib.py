@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _lib = None
 
@@ -77,7 +77,7 @@ SIGNATURES = {
     'bdv_dropout': (c_int, [P, P, c_int64, c_float, c_uint64, P]),
     'bdv_lsc_loss': (c_int, [P, P, P, c_float, c_int, P, P, P, c_int, c_int, P]),
     'bdv_softce_loss': (c_int, [P, P, P, P, P, c_int, c_int, P]),
-    'bdv_icarl_targets': (c_int, [P, P, c_int, P, c_int, c_int, P]),
+    'bdv_icarl_targets': (c_int, [P, P, c_int, P, P, c_int, c_int, P]),
     'bdv_acm_targets': (c_int, [P, P, P, c_float, P, c_int, c_int, P]),
     'bdv_softmax_mean': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_topk_acc': (c_int, [P, P, P, c_int, c_int, P]),

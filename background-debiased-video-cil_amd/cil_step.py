@@ -56,16 +56,79 @@ _soft_ce = SoftTargetCrossEntropy()
 def icarl_training_step(current_model: nn.Module, batch_data: Dict[str, torch.Tensor], num_classes: int,
                         current_task: int = 0, prev_model: Optional[nn.Module] = None,
                         previous_task_num_classes: int = 0) -> torch.Tensor:
-    """libs/cil/icarl.py:97-125 (without the ActorCutMix ``foreground_ratio`` branch, which is out of scope).
-    The prev model is evaluated on the whole batch and only old-class rows are used (same values as the
-    reference's ``imgs[indices]`` gather: eval-mode BN makes rows independent)."""
+    """libs/cil/icarl.py:97-125, including the soft labels of the ``foreground_ratio`` branch (:103-111; like the
+    reference it rewrites ``batch_data['background_label']`` -1 -> 0 in place).  The prev model is evaluated on the whole
+    batch and only old-class rows are used (same values as the reference's ``imgs[indices]`` gather: eval-mode BN makes
+    rows independent)."""
     imgs, targets = batch_data['imgs'], batch_data['label']
+    cls_score = current_model(imgs, return_loss=False)
+    base = None
+    if 'foreground_ratio' in batch_data:
+        background_labels = torch.squeeze(batch_data['background_label'], dim=1)
+        background_labels[background_labels == -1] = 0
+        fg = batch_data['foreground_ratio'].reshape(-1).to(torch.float32).contiguous()
+        base = K.acm_targets(targets.reshape(-1).contiguous(), background_labels.contiguous(), fg, 4.0, num_classes)
+    prev_logits = None
+    if current_task > 0 and prev_model is not None:
+        with torch.no_grad():
+            prev_logits = prev_model(imgs, return_loss=False)
+    return _soft_ce(cls_score, targets.view(-1), prev_logits=prev_logits, prev_num_classes=previous_task_num_classes,
+                    base_targets=base)
+
+
+def tubemix_draw(batch_size: int, rows: int, cols: int, alpha, prob: float):
+    """The random decisions of ``tubemix`` / ``rand_bbox`` (libs/cil/icarl_video_mix.py:48-81) in the reference's order:
+    ``random.random()``, ``torch.randperm``, ``np.random.beta``, two ``np.random.randint``.  Returns None (no mix) or
+    ``(batch_idx, (r1, c1, r2, c2), lam)`` with the box over (rows, cols) = the last two dimensions of the clips and
+    ``lam`` the area-corrected mixing weight.  (``np.int`` of the reference is spelled ``int`` here: it no longer exists
+    in the numpy of this image.)"""
+    import random
+
+    import numpy as np
+    if prob < 0:
+        raise ValueError('prob must be a positive value')
+    if not (random.random() > 1 - prob):
+        return None
+    batch_idx = torch.randperm(batch_size)
+    lam = np.random.beta(alpha, alpha)
+    cut_rat = np.sqrt(1. - lam)
+    cut_r, cut_c = int(np.asarray(rows * cut_rat).reshape(-1)[0]), int(np.asarray(cols * cut_rat).reshape(-1)[0])
+    cr, cc = np.random.randint(rows), np.random.randint(cols)
+    r1, c1 = int(np.clip(cr - cut_r // 2, 0, rows)), int(np.clip(cc - cut_c // 2, 0, cols))
+    r2, c2 = int(np.clip(cr + cut_r // 2, 0, rows)), int(np.clip(cc + cut_c // 2, 0, cols))
+    lam = 1 - ((r2 - r1) * (c2 - c1) / (cols * rows))
+    return batch_idx, (r1, c1, r2, c2), float(lam)
+
+
+def icarl_video_mix_training_step(current_model: nn.Module, batch_data: Dict[str, torch.Tensor], num_classes: int,
+                                  video_mix_prob: float, video_mix_alpha, current_task: int = 0,
+                                  prev_model: Optional[nn.Module] = None, previous_task_num_classes: int = 0) -> torch.Tensor:
+    """``ICARLVideoMix.training_step`` (libs/cil/icarl_video_mix.py:20-45): with probability ``video_mix_prob`` a box of
+    every frame is overwritten, in place, by the same box of a permuted sample and the one-hot targets are mixed by the
+    box area; then the iCaRL step on the mixed clips.  ``imgs`` must be the (B, T, 3, H, W) tensor (the box copy is a
+    strided tensor copy).  The config's ``video_mix_alpha`` reaches ``np.random.beta`` as a 1-tuple in the reference
+    (trailing comma at :22); pass the config value, the tuple is made here."""
+    imgs, labels = batch_data['imgs'], batch_data['label']
+    if not torch.is_tensor(imgs) or imgs.dim() != 5:
+        raise TypeError('icarl_video_mix_training_step needs imgs as a (B, T, 3, H, W) tensor')
+    alpha = (video_mix_alpha,)
+    draw = tubemix_draw(imgs.size(0), imgs.size(-2), imgs.size(-1), alpha, video_mix_prob)
+    base = None
+    if draw is not None:
+        batch_idx, (r1, c1, r2, c2), lam = draw
+        perm = batch_idx.to(imgs.device)
+        imgs[:, :, :, r1:r2, c1:c2] = imgs[perm][:, :, :, r1:r2, c1:c2]
+        flat = labels.reshape(-1).contiguous()
+        lam_t = torch.full((flat.numel(),), lam, dtype=torch.float32, device=imgs.device)
+        # y * lam + y[batch_idx] * (1 - lam) on one-hot rows = the smooth-label kernel with exponent 1
+        base = K.acm_targets(flat, flat[perm].contiguous(), lam_t, 1.0, num_classes)
     cls_score = current_model(imgs, return_loss=False)
     prev_logits = None
     if current_task > 0 and prev_model is not None:
         with torch.no_grad():
             prev_logits = prev_model(imgs, return_loss=False)
-    return _soft_ce(cls_score, targets.view(-1), prev_logits=prev_logits, prev_num_classes=previous_task_num_classes)
+    return _soft_ce(cls_score, labels.view(-1), prev_logits=prev_logits, prev_num_classes=previous_task_num_classes,
+                    base_targets=base)
 
 
 class TrainEngine:

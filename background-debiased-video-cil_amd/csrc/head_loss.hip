@@ -371,7 +371,8 @@ __global__ __launch_bounds__(256) void softce_kernel(const float* __restrict__ s
 
 // one wave per row: targets = onehot or softmax(prev logits) for old-class samples
 __global__ __launch_bounds__(256) void icarl_targets_kernel(const int64_t* __restrict__ labels, const float* __restrict__ prev,
-                                                             int prevK, float* __restrict__ tgt, int B, int K) {
+                                                             int prevK, const float* __restrict__ base, float* __restrict__ tgt,
+                                                             int B, int K) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void icarl_targets_kernel(const int64_t* __res
     es = wave_sum(es);
     for (int k = lane; k < K; k += 64) tgt[(size_t)b * K + k] = expf(row[k] - mx) / es;
   } else {
-    for (int k = lane; k < K; k += 64) tgt[(size_t)b * K + k] = (k == y) ? 1.f : 0.f;
+    for (int k = lane; k < K; k += 64) tgt[(size_t)b * K + k] = base != nullptr ? base[(size_t)b * K + k] : ((k == y) ? 1.f : 0.f);
   }
 }
 
@@ -594,10 +595,12 @@ extern "C" int bdv_softce_loss(const float* score, const float* soft_targets, co
   return BDV_OK;
 }
 
-extern "C" int bdv_icarl_targets(const int64_t* labels, const float* prev_logits, int prev_K, float* targets, int B, int K,
-                                 void* stream) {
+extern "C" int bdv_icarl_targets(const int64_t* labels, const float* prev_logits, int prev_K, const float* base_targets,
+                                 float* targets, int B, int K, void* stream) {
   BDV_REQUIRE(labels && targets && B > 0 && K > 0, "bdv_icarl_targets: bad argument");
-  hipLaunchKernelGGL(icarl_targets_kernel, dim3((B + 3) / 4), dim3(256), 0, HL_STREAM, labels, prev_logits, prev_K, targets, B, K);
+  BDV_REQUIRE(base_targets != targets, "bdv_icarl_targets: base_targets must not alias targets");
+  hipLaunchKernelGGL(icarl_targets_kernel, dim3((B + 3) / 4), dim3(256), 0, HL_STREAM, labels, prev_logits, prev_K, base_targets,
+                     targets, B, K);
   BDV_LAUNCH_CHECK("bdv_icarl_targets");
   return BDV_OK;
 }

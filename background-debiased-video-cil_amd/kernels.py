@@ -526,14 +526,18 @@ def softce_loss(score, soft_targets=None, labels=None):
     return loss[0], dscore
 
 
-def icarl_targets(labels, prev_logits, prev_K, K):
+def icarl_targets(labels, prev_logits, prev_K, K, base_targets=None):
+    """(B, K) targets of ICARLModel.training_step: ``base_targets`` (or one-hot), old-class rows <- softmax(prev logits)."""
     B = labels.numel()
     labels = labels.reshape(B)
     _chk(labels, (B,), dtype=torch.int64, name='labels')
     if prev_logits is not None:
         _chk(prev_logits, (B, K), name='prev_logits')
+    if base_targets is not None:
+        _chk(base_targets, (B, K), name='base_targets')
     tgt = torch.empty((B, K), dtype=torch.float32, device=labels.device)
-    check(lib().bdv_icarl_targets(_p(labels), _p(prev_logits), int(prev_K), _p(tgt), B, K, _stream()), 'bdv_icarl_targets')
+    check(lib().bdv_icarl_targets(_p(labels), _p(prev_logits), int(prev_K), _p(base_targets), _p(tgt), B, K, _stream()),
+          'bdv_icarl_targets')
     return tgt
 
 

@@ -56,11 +56,12 @@ class CrossEntropyLoss(nn.Module):
 @LOSSES.register_module()
 class SoftTargetCrossEntropy(nn.Module):
     """Loss of ``ICARLModel.training_step`` (libs/cil/icarl.py:101-125): one-hot targets whose old-class
-    rows are replaced by softmax(prev-model logits); ``mean_b(-sum_k tgt * log_softmax(score))``."""
+    rows are replaced by softmax(prev-model logits); ``mean_b(-sum_k tgt * log_softmax(score))``.  ``base_targets``
+    (B, K) replaces the one-hot rows (the foreground-ratio soft labels of icarl.py:103-111)."""
 
-    def forward(self, cls_score, labels, prev_logits=None, prev_num_classes=0, **kwargs):
+    def forward(self, cls_score, labels, prev_logits=None, prev_num_classes=0, base_targets=None, **kwargs):
         tgt = K.icarl_targets(labels.reshape(-1).contiguous(), None if prev_logits is None else prev_logits.contiguous(),
-                              prev_num_classes, cls_score.shape[1])
+                              prev_num_classes, cls_score.shape[1], base_targets)
         return Fn.SoftCEFn.apply(cls_score, tgt, None)
 
 

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .cil_step import base_training_step, icarl_training_step
+from .cil_step import base_training_step, icarl_training_step, icarl_video_mix_training_step
 from .ddp import GradAllReducer, broadcast_parameters
 from .hooks import OutputHook
 from .optim import build_lr_scheduler, build_optimizer
@@ -337,7 +337,7 @@ class CILTaskLoop:
         self.ending_task = config.get('ending_task', len(self.splits.task_splits) - 1)
         self.num_tasks = min(len(self.splits.task_splits), self.ending_task + 1)
         self.method = config.get('methods', 'base')
-        if self.method not in ('base', 'icarl'):
+        if self.method not in ('base', 'icarl', 'icarl_video_mix'):
             raise ValueError(self.method)
         self.use_kd = 'kd_modules_names' in config and self.method == 'base'
         self.rank = dist.get_rank() if dist.is_initialized() else 0
@@ -446,6 +446,11 @@ class CILTaskLoop:
     # -- one fit ---------------------------------------------------------------------------------------------------------
     def _training_step(self, batch_data: Dict) -> Dict:
         t = self._current_task
+        if self.method == 'icarl_video_mix':
+            loss = icarl_video_mix_training_step(self.current_model, batch_data, self.num_classes(t), self.config.video_mix_prob,
+                                                 self.config.video_mix_alpha, current_task=t, prev_model=self.prev_model,
+                                                 previous_task_num_classes=self.num_classes(t - 1))
+            return {'loss': loss, 'loss_cls': loss}
         if self.method == 'icarl':
             loss = icarl_training_step(self.current_model, batch_data, self.num_classes(t), current_task=t,
                                        prev_model=self.prev_model, previous_task_num_classes=self.num_classes(t - 1))

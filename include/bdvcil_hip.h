@@ -210,9 +210,10 @@ int bdv_lsc_loss(const float* sim, const int64_t* targets, const float* eta, flo
  * `soft_targets` (B,K) or NULL with integer `labels` (B) (= plain mean cross-entropy). */
 int bdv_softce_loss(const float* score, const float* soft_targets, const int64_t* labels, float* loss,
                     float* dscore, int B, int K, void* stream);
-/* icarl.py:101,113-120: targets = onehot(label); rows with label < prev_K <- softmax(prev_logits) */
-int bdv_icarl_targets(const int64_t* labels, const float* prev_logits, int prev_K, float* targets,
-                      int B, int K, void* stream);
+/* icarl.py:101-120: targets = base_targets (the foreground-ratio soft labels of :103-111, built by bdv_acm_targets with
+ * alpha = 4) or, when base_targets is NULL, onehot(label); rows with label < prev_K <- softmax(prev_logits). */
+int bdv_icarl_targets(const int64_t* labels, const float* prev_logits, int prev_K, const float* base_targets,
+                      float* targets, int B, int K, void* stream);
 /* libs/losses/acm_smooth_ce.py:18-28 (ACMSmoothCE smooth labels): targets = onehot(label) * lam + (1 - lam) *
  * onehot(background_label), lam = 1 - (1 - foreground_ratio)^alpha; background label -1 counts as class 0. */
 int bdv_acm_targets(const int64_t* labels, const int64_t* background_labels, const float* foreground_ratio, float alpha,

@@ -276,14 +276,49 @@ def soft_target_ce(cls_score: torch.Tensor, targets: torch.Tensor) -> torch.Tens
 
 
 def icarl_targets(labels: torch.Tensor, num_classes: int, prev_logits: Optional[torch.Tensor],
-                  prev_num_classes: int) -> torch.Tensor:
-    """icarl.py:101,113-120: one-hot, rows of old-class samples replaced by softmax(prev logits)."""
+                  prev_num_classes: int, background_label: Optional[torch.Tensor] = None,
+                  foreground_ratio: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """icarl.py:101-120: one-hot (mixed with the background label by lambda = 1 - (1 - foreground_ratio)^4 when the
+    ActorCutMix keys are present, :103-111), rows of old-class samples replaced by softmax(prev logits)."""
     tgt = F.one_hot(labels.view(-1), num_classes).float()
+    if foreground_ratio is not None:
+        bg = torch.squeeze(background_label, dim=1).clone()
+        bg[bg == -1] = 0
+        bg = F.one_hot(bg, num_classes).float()
+        lam = 1 - (1 - foreground_ratio) ** 4
+        lam = lam.view(lam.size(0), 1)
+        tgt = (tgt * lam + (1 - lam) * bg).float()
     if prev_logits is not None:
         old = (labels.view(-1) < prev_num_classes).nonzero().squeeze(1)
         if old.numel():
             tgt[old] = torch.softmax(prev_logits[old], dim=1)
     return tgt
+
+
+def tubemix(x: torch.Tensor, y: torch.Tensor, alpha, prob: float):
+    """libs/cil/icarl_video_mix.py:48-81 (tubemix + rand_bbox) on a (B, T, 3, H, W) clip batch and (B, K) one-hot targets,
+    drawing from ``random`` / ``torch`` / ``np.random`` in the reference's order.  ``np.int`` is spelled ``int``.
+    Parity unpinned: the reference function cannot run on this image's numpy (np.int was removed)."""
+    import random
+
+    import numpy as np
+    if prob < 0:
+        raise ValueError('prob must be a positive value')
+    k = random.random()
+    if k > 1 - prob:
+        batch_idx = torch.randperm(x.size(0))
+        lam = np.random.beta(alpha, alpha)
+        size = x[:, :, 0, :, :].size()
+        W_, H_ = size[2], size[3]
+        cut_rat = np.sqrt(1. - lam)
+        cut_w, cut_h = int(np.asarray(W_ * cut_rat).reshape(-1)[0]), int(np.asarray(H_ * cut_rat).reshape(-1)[0])
+        cx, cy = np.random.randint(W_), np.random.randint(H_)
+        bbx1, bby1 = np.clip(cx - cut_w // 2, 0, W_), np.clip(cy - cut_h // 2, 0, H_)
+        bbx2, bby2 = np.clip(cx + cut_w // 2, 0, W_), np.clip(cy + cut_h // 2, 0, H_)
+        x[:, :, :, bbx1:bbx2, bby1:bby2] = x[batch_idx, :, :, bbx1:bbx2, bby1:bby2]
+        lam = 1 - ((bbx2 - bbx1) * (bby2 - bby1) / (x.size()[-1] * x.size()[-2]))
+        return x, y * lam + y[batch_idx] * (1 - lam)
+    return x, y
 
 
 def acm_smooth_ce(cls_score: torch.Tensor, labels: torch.Tensor, background_label: torch.Tensor,

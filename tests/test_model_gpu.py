@@ -4,8 +4,11 @@ Bars (BASELINE.json north_star): logits within 1e-3 (fp32), label indices bit-ex
 parameters within 1e-3 of their scale.  Dropout is 0 in parity runs (RNG streams differ by design)."""
 import copy
 
+import numpy as np
+
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import tsm_oracle as O
 
@@ -175,6 +178,19 @@ def test_icarl_step(dev):
     rp, op = dict(ref.named_parameters()), dict(mod.named_parameters())
     for name in ['backbone.conv1.conv.weight', 'backbone.layer4.1.conv2.conv.weight', 'cls_head.fc_cls.weight', 'cls_head.fc_cls.bias']:
         assert _rel_l2(op[name].grad, rp[name].grad) <= 2e-2, name
+    # ActorCutMix keys in the batch: foreground-ratio soft labels (icarl.py:103-111), then the old-class rows
+    g = torch.Generator().manual_seed(4)
+    bg_label = torch.randint(-1, K, (4, 1), generator=g)
+    bg_label[2, 0] = -1
+    fg_ratio = torch.rand(4, 1, generator=g)
+    tgt = O.icarl_targets(labels, K, prev_logits, prevK, bg_label, fg_ratio)
+    with torch.no_grad():
+        rloss2 = O.soft_target_ce(ref(imgs, return_loss=False), tgt)
+    batch = dict(imgs=imgs.to(dev), label=labels.to(dev), background_label=bg_label.clone().to(dev), foreground_ratio=fg_ratio.to(dev))
+    with torch.no_grad():
+        oloss2 = bd.icarl_training_step(mod, batch, K, current_task=1, prev_model=mod_prev, previous_task_num_classes=prevK)
+    assert abs(oloss2.item() - rloss2.item()) <= 1e-4 * max(1.0, abs(rloss2.item())) and abs(rloss2.item() - rloss.item()) > 1e-3
+    assert int(batch['background_label'].min()) == 0                       # rewritten in place, as the reference does
 
 
 def test_frontend_into_model(dev):
@@ -296,3 +312,43 @@ def test_training_step_is_run_to_run_deterministic(dev):
     assert torch.equal(l1, l2)
     for n in g1:
         assert torch.equal(g1[n], g2[n]), n
+
+
+def test_icarl_video_mix_step(dev):
+    """ICARLVideoMix.training_step: tube-mix of the clips and targets, then the iCaRL soft-target step; the draws come
+    from the same generators in the same order as the CPU restatement (parity unpinned: see oracle.tubemix)."""
+    import random
+    import bdvcil_amd as bd
+    K, prevK = 9, 4
+    ref, mod, _ = _pair(18, 'SimpleLinear', 'CrossEntropyLoss', K=K, dev=dev)
+    ref_prev, mod_prev, _ = _pair(18, 'SimpleLinear', 'CrossEntropyLoss', K=K, dev=dev, seed=9)
+    for m in (ref, mod, ref_prev, mod_prev):
+        m.test_cfg['average_clips'] = 'score'
+    ref.train(); mod.train(); ref_prev.eval(); mod_prev.eval()
+    imgs, labels = _clips(4, 8, 64, K)
+    labels[0, 0], labels[3, 0] = 2, 7
+    mixed_steps = 0
+    for seed in range(4):
+        def seeds():
+            random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        seeds()
+        x = imgs.clone()
+        xm, tgt = O.tubemix(x, F.one_hot(labels.view(-1), K).float(), (0.8,), 0.6)
+        mixed_steps += int(not torch.equal(xm, imgs))
+        with torch.no_grad():
+            score = ref(xm, return_loss=False)
+            prev_logits = ref_prev(xm, return_loss=False)
+        old = (labels.view(-1) < prevK).nonzero().squeeze(1)
+        tgt = tgt.clone()
+        tgt[old] = torch.softmax(prev_logits[old], dim=1)
+        rloss = O.soft_target_ce(score, tgt)
+        seeds()
+        xg = imgs.clone().to(dev)
+        with torch.no_grad():
+            oloss = bd.icarl_video_mix_training_step(mod, dict(imgs=xg, label=labels.to(dev)), K, 0.6, 0.8, current_task=1,
+                                                     prev_model=mod_prev, previous_task_num_classes=prevK)
+        assert torch.equal(xg.cpu(), xm)                                   # the same box from the same permuted samples
+        assert abs(oloss.item() - rloss.item()) <= 1e-4 * max(1.0, abs(rloss.item())), seed
+    assert 0 < mixed_steps < 4
+    with pytest.raises(ValueError):
+        bd.tubemix_draw(4, 8, 8, (0.8,), -0.1)

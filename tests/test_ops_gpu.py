@@ -193,6 +193,9 @@ def test_consensus_softce_icarl_topk(dev):
     prev = torch.randn(B, Kc, generator=g)
     prevK = 20
     tgt_ref = O.icarl_targets(y, Kc, prev, prevK)
+    bgl, fgr = torch.randint(-1, Kc, (y.numel(), 1), generator=g), torch.rand(y.numel(), 1, generator=g)
+    base = K.acm_targets(y.to(dev), bgl.view(-1).clamp(min=0).to(dev), fgr.view(-1).to(dev), 4.0, Kc)
+    _close(K.icarl_targets(y.to(dev), prev.to(dev), prevK, Kc, base), O.icarl_targets(y, Kc, prev, prevK, bgl, fgr), tol=1e-6)
     tgt = K.icarl_targets(y.to(dev), prev.to(dev), prevK, Kc)
     _close(tgt, tgt_ref, tol=1e-5, atol=1e-7)
     sc2 = sc.detach().clone().requires_grad_(True)
