@@ -36,8 +36,16 @@ def base_training_step(current_model: nn.Module, batch_data: Dict[str, torch.Ten
             cur = current_hooks.get_layer_output(m_name)
             prev = prev_hooks.get_layer_output(m_name).detach()
             if kd_exemplar_only:
-                raise NotImplementedError('kd_exemplar_only=True is not used by the shipped configs (cil.py:529-536)')
-            kd_loss = Fn.kd_mse(cur, prev)
+                # cil.py:529-536: rows of the hooked tensors selected by the batch positions of the old-class samples.
+                # (The first dimension of the backbone features is frames, not samples; the reference indexes it with
+                # sample positions all the same, and so does this.)
+                indices = (batch_data['label'].view(-1) < previous_task_num_classes).nonzero().reshape(-1)
+                if indices.nelement():
+                    kd_loss = Fn.kd_mse(cur.index_select(0, indices).contiguous(), prev.index_select(0, indices).contiguous())
+                else:
+                    kd_loss = 0
+            else:
+                kd_loss = Fn.kd_mse(cur, prev)
             losses[m_name] = kd_loss
             total_kd_loss = total_kd_loss + scale_factor * kd_weight * kd_loss
         losses['kd_loss'] = total_kd_loss

@@ -537,8 +537,9 @@ class FeatureTap:
 
 def kd_training_step(cur: CILRecognizer2D, prev: Optional[CILRecognizer2D], cur_tap: FeatureTap,
                      prev_tap: Optional[FeatureTap], imgs, labels, kd_names: Sequence[str],
-                     kd_weights: Sequence[float], scale_factor: float, use_kd: bool) -> Dict[str, torch.Tensor]:
-    """cil.py:512-556 with kd_exemplar_only=False."""
+                     kd_weights: Sequence[float], scale_factor: float, use_kd: bool, kd_exemplar_only: bool = False,
+                     previous_task_num_classes: int = 0) -> Dict[str, torch.Tensor]:
+    """cil.py:512-556."""
     losses = cur(imgs, labels, batch_data=None)
     if use_kd and prev is not None:
         prev.eval()
@@ -546,7 +547,12 @@ def kd_training_step(cur: CILRecognizer2D, prev: Optional[CILRecognizer2D], cur_
             prev.forward_test(imgs)
         total = 0.0
         for name, w in zip(kd_names, kd_weights):
-            mse = F.mse_loss(cur_tap.out[name], prev_tap.out[name].detach())
+            c, p = cur_tap.out[name], prev_tap.out[name].detach()
+            if kd_exemplar_only:                                                   # cil.py:529-536
+                indices = (labels.view(-1) < previous_task_num_classes).nonzero().squeeze()
+                mse = F.mse_loss(c[indices], p[indices]) if indices.nelement() else 0
+            else:
+                mse = F.mse_loss(c, p)
             losses[name] = mse
             total = total + scale_factor * w * mse
         losses['kd_loss'] = total

@@ -155,6 +155,39 @@ def test_kd_step_and_hooks(dev):
         assert _rel_l2(op[name].grad, rp[name].grad) <= 2e-2, name
 
 
+@pytest.mark.parametrize('old_rows', [[0], [0, 1], []])
+def test_kd_step_exemplar_only(old_rows, dev):
+    """kd_exemplar_only=True (cil.py:529-536): the KD terms use only the tensor rows at the batch positions of old-class
+    samples (one, several, none)."""
+    import bdvcil_amd as bd
+    K, prevK = 11, 5
+    names = ['backbone.layer2', 'backbone.layer4', 'cls_head.avg_pool']
+    ref, mod, cfg = _pair(18, 'LocalSimilarityClassifier', 'LSCLoss', K=K, dev=dev)
+    ref_prev, mod_prev, _ = _pair(18, 'LocalSimilarityClassifier', 'LSCLoss', K=K, dev=dev, seed=5)
+    imgs, labels = _clips(2, 8, 64, K)
+    labels[:, 0] = torch.tensor([7, 9])
+    for r in old_rows:
+        labels[r, 0] = r + 1
+    rt, rpt = O.FeatureTap(ref, names), O.FeatureTap(ref_prev, names)
+    ref.train()
+    rl = O.kd_training_step(ref, ref_prev, rt, rpt, imgs, labels, names, [0.5] * 3, 2.0, True, True, prevK)
+    rl['loss'].backward()
+    ch, ph = bd.OutputHook(mod, names), bd.OutputHook(mod_prev, names)
+    mod.train()
+    ol = bd.base_training_step(mod, dict(imgs=imgs.to(dev), label=labels.to(dev)), current_task=1, prev_model=mod_prev,
+                               current_hooks=ch, prev_hooks=ph, kd_modules_names=names, kd_weight_by_module=[0.5] * 3,
+                               adaptive_scale_factors=[1.0, 2.0], kd_exemplar_only=True, previous_task_num_classes=prevK)
+    ol['loss'].backward()
+    for n in names:
+        a, b = (float(v.detach()) if torch.is_tensor(v) else float(v) for v in (ol[n], rl[n]))
+        assert abs(a - b) <= 1e-4 * max(1e-3, abs(b)), n
+        assert (b == 0) == (not old_rows)
+    assert abs(ol['loss'].item() - rl['loss'].item()) <= 1e-4 * max(1.0, abs(rl['loss'].item()))
+    rp, op = dict(ref.named_parameters()), dict(mod.named_parameters())
+    for name in ['backbone.conv1.conv.weight', 'backbone.layer4.1.conv2.conv.weight', 'cls_head.fc_cls.weights']:
+        assert _rel_l2(op[name].grad, rp[name].grad) <= 2e-2, name
+
+
 def test_icarl_step(dev):
     import bdvcil_amd as bd
     K, prevK = 11, 6
