@@ -9,7 +9,10 @@ Parity pinning status
   (``tests/golden/make_golden.py`` -> ``tests/golden/head_loss_golden.npz``):
   ``lsc_forward`` / ``LSC`` (libs/models/cil_heads/cosine_linear.py:27-43),
   ``IncrementalNet`` (libs/models/cil_heads/inc_net.py:23-37),
-  ``lsc_loss`` (libs/losses/lsc_loss.py:30-58).
+  ``lsc_loss`` (libs/losses/lsc_loss.py:30-58); ``acm_smooth_ce`` -- and with it the foreground-ratio soft labels of
+  ``icarl_targets`` -- by ``tests/golden/acm_golden.npz`` (libs/losses/acm_smooth_ce.py:13-30).
+* PARITY UNPINNED: ``tubemix`` (libs/cil/icarl_video_mix.py:48-81 uses ``np.int``, which this image's numpy no longer
+  has, and sits behind Lightning imports).
 * PARITY UNPINNED: everything that lives in un-vendored mmaction2 0.24.x / mmcv 1.x
   (ResNet, TemporalShift, TSMHead, Recognizer2D, BaseHead.loss, Normalize).  Those
   packages are absent from /root/reference and from this image; the restatement
