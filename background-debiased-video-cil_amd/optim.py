@@ -65,13 +65,29 @@ class FusedSGD(torch.optim.Optimizer):
         key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]['momentum_buffer'].data_ptr()) for _, p in active)
         hyper = tuple((self.param_groups[gi]['lr'], self.param_groups[gi]['weight_decay']) for gi, _ in active)
         t = self._tables
-        if t is None or t['key'] != key:
-            t = dict(key=key, hyper=None,
-                     p=torch.tensor([k[0] for k in key], dtype=torch.int64, device=dev),
-                     g=torch.tensor([k[1] for k in key], dtype=torch.int64, device=dev),
-                     b=torch.tensor([k[2] for k in key], dtype=torch.int64, device=dev),
-                     n=torch.tensor([p.numel() for _, p in active], dtype=torch.int64, device=dev))
+        n = len(active)
+        if t is None or t['count'] != n or t['dev'] != dev:
+            table = torch.empty(4 * n, dtype=torch.int64, device=dev)
+            t = dict(key=None, hyper=None, count=n, dev=dev, table=table, p=table[:n], g=table[n:2 * n], b=table[2 * n:3 * n],
+                     n=table[3 * n:], staging=[torch.empty(4 * n, dtype=torch.int64).pin_memory() for _ in range(4)],
+                     events=[None] * 4, slot=0)
             self._tables = t
+        if t['key'] != key:
+            # Gradients are fresh allocations every step (zero_grad(set_to_none=True)), so the pointer table changes every
+            # step.  It goes to the device through a ring of pinned staging buffers with an asynchronous copy: a pageable
+            # copy would make the host wait here for the whole backward pass.
+            i = t['slot']
+            t['slot'] = (i + 1) % len(t['staging'])
+            if t['events'][i] is not None:
+                t['events'][i].synchronize()                   # the copy issued from this buffer four rebuilds ago
+            st = t['staging'][i]
+            st[:3 * n].view(3, n).copy_(torch.tensor(key, dtype=torch.int64).t())
+            st[3 * n:].copy_(torch.tensor([p.numel() for _, p in active], dtype=torch.int64))
+            t['table'].copy_(st, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            t['events'][i] = ev
+            t['key'] = key
         if t['hyper'] != hyper:
             t['hyper'] = hyper
             t['lr'] = torch.tensor([h[0] for h in hyper], dtype=torch.float32, device=dev)
