@@ -385,3 +385,47 @@ def test_icarl_video_mix_step(dev):
     assert 0 < mixed_steps < 4
     with pytest.raises(ValueError):
         bd.tubemix_draw(4, 8, 8, (0.8,), -0.1)
+
+
+def test_full_size_step_properties(dev):
+    """BASELINE config 2 at its full size (TSM-R50, 32 x 8 x 3 x 224 x 224, 101 classes), where the CPU oracle would take
+    minutes: properties that hold for any correct implementation.
+
+    * eval mode (running statistics): clips are independent, so the logits of the first four clips of the batch equal a
+      batch-of-four run (the tile schedule differs, hence a tolerance), with identical labels;
+    * train step with mean cross-entropy: the logit gradients of every sample sum to zero, so the classifier bias gradient
+      sums to zero; every gradient is finite; the step is reproducible bit for bit;
+    * linearity of backward: doubling the loss doubles every gradient (exactly: powers of two)."""
+    import bdvcil_amd as bd
+    torch.manual_seed(0)
+    cfg = O.r50_cfg(num_classes=101, depth=50, head='SimpleLinear', loss='CrossEntropyLoss', dropout_ratio=0.0)
+    mod = bd.build_model(copy.deepcopy(cfg)).to(dev)
+    imgs, labels = _clips(32, 8, 224, 101)
+    imgs, labels = imgs.to(dev), labels.to(dev)
+    mod.eval()
+    with torch.no_grad():
+        full = mod(imgs, return_loss=False)
+        part = mod(imgs[:4].contiguous(), return_loss=False)
+    assert full.shape == (32, 101)
+    assert (full[:4] - part).abs().max().item() <= 1e-4 * max(1.0, full.abs().max().item())
+    assert torch.equal(full[:4].argmax(1), part.argmax(1))
+    mod.train()
+
+    def grads(scale):
+        for p in mod.parameters():
+            p.grad = None
+        bn = {k: v.clone() for k, v in mod.state_dict().items() if 'running' in k or 'num_batches' in k}
+        out = mod(imgs, labels)
+        (out['loss_cls'] * scale).backward()
+        mod.load_state_dict(bn, strict=False)                      # same running statistics for the next call
+        return float(out['loss_cls'].detach()), {n: p.grad.clone() for n, p in mod.named_parameters()}
+    l1, g1 = grads(1.0)
+    l1b, g1b = grads(1.0)
+    l2, g2 = grads(2.0)
+    assert l1 == l1b == l2 and np.isfinite(l1)
+    bias = g1['cls_head.fc_cls.fc.bias'] if 'cls_head.fc_cls.fc.bias' in g1 else g1['cls_head.fc_cls.bias']
+    assert abs(float(bias.sum())) <= 1e-5 and float(bias.abs().max()) > 1e-4
+    for n in g1:
+        assert torch.isfinite(g1[n]).all(), n
+        assert torch.equal(g1[n], g1b[n]), n                        # run-to-run deterministic
+        assert torch.equal(g2[n], g1[n] * 2), n                     # backward is linear in the loss gradient
