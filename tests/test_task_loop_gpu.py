@@ -51,8 +51,11 @@ def _config(tmp, **over):
 
 
 def _loop(cfg, seed=0):
+    import random
     import bdvcil_amd.task_loop as TL
     torch.manual_seed(1234)
+    random.seed(1234)                  # RandAugment of the synthetic train loader draws from these two
+    np.random.seed(1234)
     loader = TL.SyntheticClipLoader('cuda', num_segments=8, size=SIZE, seed=5)
     return TL.CILTaskLoop(cfg, loader, device='cuda', seed=seed, log=lambda *a: None)
 
