@@ -1070,11 +1070,11 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
 }
 
 // dw = beta*dw + sum over splits (fixed order).  64 float4 elements x 4 split-lanes per block.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, float beta,
-                                                            int splits, int64_t numel4) {
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ slab, float* __restrict__ dw, float beta, int splits,
+                                                   int64_t numel4, int block) {
   __shared__ float4 sh[4][64];
   const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + el;
+  const int64_t i = (int64_t)block * 64 + el;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < numel4) {
     for (int k = sg; k < splits; k += 4) {
@@ -1106,6 +1106,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     *d = s;
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, float beta,
+                                                            int splits, int64_t numel4) {
+  wgrad_reduce_block(slab, dw, beta, splits, numel4, blockIdx.x);
+}
+
+// The same reduction for up to BDV_MAX_REDUCE_ITEMS weight gradients in one launch (one stage's worth): block b works on
+// the item whose block range contains it.  Per element the summation order is that of wgrad_reduce_kernel.
+struct ReduceBatch {
+  const float* slab[BDV_MAX_REDUCE_ITEMS];
+  float* dw[BDV_MAX_REDUCE_ITEMS];
+  int splits[BDV_MAX_REDUCE_ITEMS];
+  int numel4[BDV_MAX_REDUCE_ITEMS];
+  int first_block[BDV_MAX_REDUCE_ITEMS + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(ReduceBatch rb, float beta) {
+  int k = 0;
+  while (k + 1 < rb.n && (int)blockIdx.x >= rb.first_block[k + 1]) ++k;  // uniform per block
+  wgrad_reduce_block(rb.slab[k], rb.dw[k], beta, rb.splits[k], rb.numel4[k], blockIdx.x - rb.first_block[k]);
 }
 
 // ---- host side --------------------------------------------------------------------------------
@@ -1421,22 +1443,20 @@ extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const 
   return BDV_OK;
 }
 
-extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float beta, const bdv_conv_geom* gg,
-                              void* workspace, size_t workspace_bytes, void* stream) {
-  if (int e = check_geom(gg, "bdv_conv_wgrad")) return e;
-  BDV_REQUIRE(dy && x && dw && workspace, "bdv_conv_wgrad: null pointer");
-  BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(dw) && bdv_aligned16(workspace),
-              "bdv_conv_wgrad: pointers must be 16-byte aligned");
+namespace {
+
+// main kernel of a weight gradient: split-K partial products into `slab` (plan_wgrad(gg).splits slices of dw's size)
+int wgrad_partial(const char* who, const float* dy, const float* x, const bdv_conv_geom* gg, void* workspace, size_t workspace_bytes,
+                  hipStream_t s, int* splits_out) {
   const WgradPlan p = plan_wgrad(gg);
   const size_t need = (size_t)p.splits * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(float);
   if (workspace_bytes < need) {
-    bdv_set_error("bdv_conv_wgrad: workspace %zu < required %zu bytes", workspace_bytes, need);
+    bdv_set_error("%s: workspace %zu < required %zu bytes", who, workspace_bytes, need);
     return BDV_EWORKSPACE;
   }
   Geom g = make_geom(gg);
   g.M = g.N * g.Ho * g.Wo;
   g.Ktot = g.R * g.S * g.Cin;
-  hipStream_t s = (hipStream_t)stream;
   float* slab = (float*)workspace;
   const dim3 grid(p.MTw * p.NTw * p.splits);
   if (debug_plan())
@@ -1460,10 +1480,63 @@ extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float 
     BDV_WGRAD(64, false);
   }
 #undef BDV_WGRAD
-  BDV_LAUNCH_CHECK("bdv_conv_wgrad");
-  const int64_t numel4 = (int64_t)g.Cout * g.Ktot / 4;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((numel4 + 63) / 64)), dim3(256), 0, s, (const float*)slab, dw, beta, p.splits,
+  BDV_LAUNCH_CHECK(who);
+  *splits_out = p.splits;
+  return BDV_OK;
+}
+
+}  // namespace
+
+extern "C" int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float beta, const bdv_conv_geom* gg,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (int e = check_geom(gg, "bdv_conv_wgrad")) return e;
+  BDV_REQUIRE(dy && x && dw && workspace, "bdv_conv_wgrad: null pointer");
+  BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(dw) && bdv_aligned16(workspace),
+              "bdv_conv_wgrad: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  int splits = 0;
+  if (int e = wgrad_partial("bdv_conv_wgrad", dy, x, gg, workspace, workspace_bytes, s, &splits)) return e;
+  const int64_t numel4 = (int64_t)gg->Cout * gg->R * gg->S * gg->Cin / 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((numel4 + 63) / 64)), dim3(256), 0, s, (const float*)workspace, dw, beta, splits,
                      numel4);
   BDV_LAUNCH_CHECK("bdv_conv_wgrad(reduce)");
+  return BDV_OK;
+}
+
+extern "C" int bdv_conv_wgrad_splits(const bdv_conv_geom* gg) {
+  if (check_geom(gg, "bdv_conv_wgrad_splits")) return 0;
+  return plan_wgrad(gg).splits;
+}
+
+extern "C" int bdv_conv_wgrad_partial(const float* dy, const float* x, const bdv_conv_geom* gg, void* slab, size_t slab_bytes,
+                                      void* stream) {
+  if (int e = check_geom(gg, "bdv_conv_wgrad_partial")) return e;
+  BDV_REQUIRE(dy && x && slab, "bdv_conv_wgrad_partial: null pointer");
+  BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(slab), "bdv_conv_wgrad_partial: pointers must be 16-byte aligned");
+  int splits = 0;
+  return wgrad_partial("bdv_conv_wgrad_partial", dy, x, gg, slab, slab_bytes, (hipStream_t)stream, &splits);
+}
+
+extern "C" int bdv_wgrad_reduce_batched(const float* const* slabs, float* const* dws, const int* splits, const int64_t* numels,
+                                        int n, float beta, void* stream) {
+  BDV_REQUIRE(slabs && dws && splits && numels, "bdv_wgrad_reduce_batched: null pointer");
+  BDV_REQUIRE(n > 0 && n <= BDV_MAX_REDUCE_ITEMS, "bdv_wgrad_reduce_batched: %d items (1..%d supported)", n, BDV_MAX_REDUCE_ITEMS);
+  ReduceBatch rb;
+  rb.n = n;
+  int blocks = 0;
+  for (int k = 0; k < n; ++k) {
+    BDV_REQUIRE(slabs[k] && dws[k] && bdv_aligned16(slabs[k]) && bdv_aligned16(dws[k]), "bdv_wgrad_reduce_batched: item %d: bad pointer", k);
+    BDV_REQUIRE(splits[k] > 0 && numels[k] > 0 && numels[k] % 4 == 0 && numels[k] / 4 < (1ll << 31),
+                "bdv_wgrad_reduce_batched: item %d: bad size", k);
+    rb.slab[k] = slabs[k];
+    rb.dw[k] = dws[k];
+    rb.splits[k] = splits[k];
+    rb.numel4[k] = (int)(numels[k] / 4);
+    rb.first_block[k] = blocks;
+    blocks += (rb.numel4[k] + 63) / 64;
+  }
+  rb.first_block[n] = blocks;
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rb, beta);
+  BDV_LAUNCH_CHECK("bdv_wgrad_reduce_batched");
   return BDV_OK;
 }

@@ -40,6 +40,8 @@ _SIDE = {'enabled': _os.environ.get('BDVCIL_WGRAD_SIDE_STREAM', '0') != '0', 'st
 FUSE_BN_STATS = _os.environ.get('BDVCIL_FUSE_BN_STATS', '1') != '0'
 # A whole stage as one autograd node (ResStageFn): lets the statistics fusion above reach the block outputs.
 FUSE_STAGE = _os.environ.get('BDVCIL_FUSE_STAGE', '1') != '0'
+# one split-K reduction launch per autograd node (stage / block) instead of one per conv
+BATCH_WGRAD_REDUCE = _os.environ.get('BDVCIL_BATCH_WGRAD_REDUCE', '1') != '0'
 
 
 def set_side_stream_enabled(flag: bool):
@@ -63,8 +65,33 @@ def join_side_stream(device=None):
             del _SIDE['pending'][idx]
 
 
+class wgrad_batch:
+    """Inside ``with wgrad_batch():`` the split-K reductions of all weight gradients are deferred and run as one launch
+    when the block ends (a stage's backward: one reduce kernel instead of one per conv).  The returned dw tensors are
+    filled at that point, i.e. before the autograd node hands them out."""
+    current = None
+
+    def __enter__(self):
+        self.items, self.outer = [], wgrad_batch.current
+        if BATCH_WGRAD_REDUCE and not _SIDE['enabled']:
+            wgrad_batch.current = self
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        wgrad_batch.current = self.outer
+        if exc_type is None and self.items:
+            K.wgrad_reduce_batched(self.items)
+        self.items = []
+        return False
+
+
 def wgrad_overlapped(dy: torch.Tensor, inp: torch.Tensor, geom) -> torch.Tensor:
-    """conv_wgrad on the side stream (same result tensor semantics as K.conv_wgrad)."""
+    """Weight gradient of one conv: deferred reduction inside a ``wgrad_batch``, otherwise K.conv_wgrad (optionally on the
+    side stream)."""
+    if wgrad_batch.current is not None:
+        slab, dw = K.conv_wgrad_partial(dy, inp, geom)
+        wgrad_batch.current.items.append((slab, dw))
+        return dw
     if not _SIDE['enabled']:
         return K.conv_wgrad(dy, inp, geom)
     main = torch.cuda.current_stream(dy.device)
@@ -322,7 +349,8 @@ class ResBlockFn(torch.autograd.Function):
         t = ctx.saved_tensors
         saved, params = t[:ctx.n_saved], t[ctx.n_saved:]
         need = ctx.needs_input_grad      # (x, blk, training, *params)
-        dx, grads, _ = _block_backward(saved, params, ctx.geoms, ctx.n_main, ctx.has_down, dout, need[3:], need[0])
+        with wgrad_batch():
+            dx, grads, _ = _block_backward(saved, params, ctx.geoms, ctx.n_main, ctx.has_down, dout, need[3:], need[0])
         return (dx, None, None, *grads)
 
 
@@ -367,18 +395,19 @@ class ResStageFn(torch.autograd.Function):
             p_off.append(p_off[-1] + m[1])
         grads_all: List[Optional[torch.Tensor]] = [None] * len(params_all)
         d, part = dout, None
-        for k in range(len(meta) - 1, -1, -1):
-            n_saved, npar, geoms, n_main, has_down = meta[k]
-            saved = saved_all[s_off[k]:s_off[k + 1]]
-            params = params_all[p_off[k]:p_off[k + 1]]
-            prev_stats = None
-            if k > 0:
-                pm = meta[k - 1]
-                prev_stats = _block_out_stats(saved_all[s_off[k - 1]:s_off[k]], pm[3])
-            need_dx = need[0] or k > 0
-            d, grads, part = _block_backward(saved, params, geoms, n_main, has_down, d, need[3 + p_off[k]:3 + p_off[k + 1]],
-                                             need_dx, out_stat_partial=part, prev_stats=prev_stats)
-            grads_all[p_off[k]:p_off[k + 1]] = grads
+        with wgrad_batch():              # one split-K reduction launch for the weight gradients of the whole stage
+            for k in range(len(meta) - 1, -1, -1):
+                n_saved, npar, geoms, n_main, has_down = meta[k]
+                saved = saved_all[s_off[k]:s_off[k + 1]]
+                params = params_all[p_off[k]:p_off[k + 1]]
+                prev_stats = None
+                if k > 0:
+                    pm = meta[k - 1]
+                    prev_stats = _block_out_stats(saved_all[s_off[k - 1]:s_off[k]], pm[3])
+                need_dx = need[0] or k > 0
+                d, grads, part = _block_backward(saved, params, geoms, n_main, has_down, d, need[3 + p_off[k]:3 + p_off[k + 1]],
+                                                 need_dx, out_stat_partial=part, prev_stats=prev_stats)
+                grads_all[p_off[k]:p_off[k + 1]] = grads
         return (d, None, None, *grads_all)
 
 

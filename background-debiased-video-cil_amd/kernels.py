@@ -407,6 +407,41 @@ def crop_normalize_u8(frames, crops, crop_h, crop_w, mean, std, want_nhwc4=True,
     return o4, oc
 
 
+def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom):
+    """Split-K partial products of a weight gradient -> (slab (splits, Cout, R, S, Cin), empty dw); reduce them later with
+    ``wgrad_reduce_batched`` (the slab must stay alive until then)."""
+    _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
+    _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
+    splits = lib().bdv_conv_wgrad_splits(ctypes.byref(g))
+    if splits <= 0:
+        check(-1, 'bdv_conv_wgrad_splits')
+    slab = torch.empty((splits, g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
+    check(lib().bdv_conv_wgrad_partial(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, _stream()), 'bdv_conv_wgrad_partial')
+    dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
+    return slab, dw
+
+
+def wgrad_reduce_batched(items, beta: float = 0.0):
+    """items: [(slab, dw), ...] from ``conv_wgrad_partial``; dw[k] = beta * dw[k] + sum over the slices of slab[k], for all
+    items in as few launches as BDV_MAX_REDUCE_ITEMS allows."""
+    MAXN = 32
+    for a in range(0, len(items), MAXN):
+        chunk = items[a:a + MAXN]
+        n = len(chunk)
+        for slab, dw in chunk:
+            _chk(slab, name='slab')
+            _chk(dw, name='dw')
+            if slab.shape[1:] != dw.shape:
+                raise ValueError(f'wgrad_reduce_batched: slab {tuple(slab.shape)} does not stack dw {tuple(dw.shape)}')
+        slabs = (ctypes.c_void_p * n)(*[s.data_ptr() for s, _ in chunk])
+        dws = (ctypes.c_void_p * n)(*[d.data_ptr() for _, d in chunk])
+        splits = (ctypes.c_int * n)(*[s.shape[0] for s, _ in chunk])
+        numels = (ctypes.c_int64 * n)(*[d.numel() for _, d in chunk])
+        check(lib().bdv_wgrad_reduce_batched(ctypes.cast(slabs, ctypes.c_void_p), ctypes.cast(dws, ctypes.c_void_p),
+                                             ctypes.cast(splits, ctypes.c_void_p), ctypes.cast(numels, ctypes.c_void_p), n,
+                                             float(beta), _stream()), 'bdv_wgrad_reduce_batched')
+
+
 # ---------------------------------------------------------------------------------------------
 # heads / losses
 # ---------------------------------------------------------------------------------------------

@@ -98,6 +98,17 @@ int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const float* add_
  * partial slabs go to `workspace`, a second kernel reduces them in fixed order. */
 int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float beta, const bdv_conv_geom* g, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* The same weight gradient in two steps, so that the split-K reductions of several layers run as ONE launch (a ResNet
+ * stage's backward issues one instead of up to 19): bdv_conv_wgrad_partial leaves bdv_conv_wgrad_splits(g) partial
+ * products of dw's size in `slab` (caller-owned, alive until reduced); bdv_wgrad_reduce_batched computes
+ * dws[k] = beta * dws[k] + sum of the splits[k] slices of slabs[k] for n <= BDV_MAX_REDUCE_ITEMS items (HOST arrays;
+ * numels[k] = elements of dws[k], a multiple of 4), with the per-element summation order of bdv_conv_wgrad. */
+#define BDV_MAX_REDUCE_ITEMS 32
+int bdv_conv_wgrad_splits(const bdv_conv_geom* g);
+int bdv_conv_wgrad_partial(const float* dy, const float* x, const bdv_conv_geom* g, void* slab, size_t slab_bytes,
+                           void* stream);
+int bdv_wgrad_reduce_batched(const float* const* slabs, float* const* dws, const int* splits, const int64_t* numels, int n,
+                             float beta, void* stream);
 
 /* ---- BatchNorm2d (train + eval), fused with ReLU / residual add --------------------------
  * Replaces UPSTREAM ConvModule.bn (+ .activate, + block `out + identity`) and their autograd.

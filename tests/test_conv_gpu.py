@@ -112,6 +112,33 @@ def test_wgrad(case, dev):
     _close(dw2.cpu(), 2 * ref)
 
 
+def test_wgrad_partial_and_batched_reduce(dev):
+    """Weight gradients left as split-K partial products and reduced together in one launch (what a stage's backward does)
+    equal the one-call form bit for bit, for a batch of layers of very different sizes."""
+    from bdvcil_amd import kernels as K
+    items, want = [], []
+    for ci, case in enumerate(CASES):
+        N, H, W, Cin, Cout, R, st, pad, T, fold = case
+        x, w = _mk(case, 2 + ci)
+        g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
+        dyd = torch.randn(N, g.Ho, g.Wo, Cout, generator=torch.Generator().manual_seed(40 + ci)).to(dev)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+        want.append(K.conv_wgrad(dyd, xd, g))
+        slab, dw = K.conv_wgrad_partial(dyd, xd, g)
+        assert slab.shape[1:] == dw.shape and slab.shape[0] >= 1
+        items.append((slab, dw))
+    items = items * 3                                    # more than BDV_MAX_REDUCE_ITEMS = 32: several launches
+    K.wgrad_reduce_batched(items)
+    for (slab, dw), ref in zip(items, want * 3):
+        assert torch.equal(dw, ref)
+    acc = [(s, d.clone()) for s, d in items[:5]]
+    K.wgrad_reduce_batched(acc, beta=1.0)
+    for (s, d), ref in zip(acc, want[:5]):
+        assert torch.equal(d, ref * 2)
+    with pytest.raises(ValueError):
+        K.wgrad_reduce_batched([(items[0][0], items[1][1])])
+
+
 def test_linearity_full_size(dev):
     """Size-independent property at a BASELINE-size site (layer3 conv2: 256->256 3x3 on 14x14, N=256):
     conv(a*x1 + x2) == a*conv(x1) + conv(x2), and the kernel is deterministic run to run."""
