@@ -48,17 +48,18 @@ __global__ void split3_kernel(const float* __restrict__ x, u16* __restrict__ pla
   planes[2 * n + i] = bf16_rn(r2);
 }
 
-template <int BM, int BN, int NPROD>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const u16* __restrict__ A, const u16* __restrict__ B, float* __restrict__ C,
+template <int BM, int BN, int NPROD, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16x3_kernel(const u16* __restrict__ A, const u16* __restrict__ B, float* __restrict__ C,
                                                            int M, int N, int K) {
-  constexpr int TM = BM / 64, TN = BN / 64;               // 32x32 tiles per wave in each direction
+  constexpr int NT = 64 * WM * WN;                        // threads
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;     // 32x32 tiles per wave in each direction
   constexpr int NPL = NPROD == 6 ? 3 : 2;                 // planes needed
-  constexpr int AV = BM * BK / 8 / 256, BV = BN * BK / 8 / 256;  // 16-byte vectors per thread per plane
+  constexpr int AV = BM * BK / 8 / NT, BV = BN * BK / 8 / NT;  // 16-byte vectors per thread per plane
   extern __shared__ __attribute__((aligned(16))) u16 smem[];  // A planes then B planes (up to 120 KB: dynamic)
   u16(*As)[BM * LDK] = reinterpret_cast<u16(*)[BM * LDK]>(smem);
   u16(*Bs)[BN * LDK] = reinterpret_cast<u16(*)[BN * LDK]>(smem + NPL * BM * LDK);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int nbn = N / BN;
   const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
   const size_t planeA = (size_t)M * K, planeB = (size_t)N * K;
@@ -70,12 +71,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const u16* __restrict_
     for (int p = 0; p < NPL; ++p) {
 #pragma unroll
       for (int v = 0; v < AV; ++v) {
-        const int idx = tid + 256 * v, row = idx >> 2, kv = idx & 3;
+        const int idx = tid + NT * v, row = idx >> 2, kv = idx & 3;
         ra[p * AV + v] = *reinterpret_cast<const u32x4*>(A + p * planeA + (size_t)(bm * BM + row) * K + kt * BK + 8 * kv);
       }
 #pragma unroll
       for (int v = 0; v < BV; ++v) {
-        const int idx = tid + 256 * v, row = idx >> 2, kv = idx & 3;
+        const int idx = tid + NT * v, row = idx >> 2, kv = idx & 3;
         rb[p * BV + v] = *reinterpret_cast<const u32x4*>(B + p * planeB + (size_t)(bn * BN + row) * K + kt * BK + 8 * kv);
       }
     }
@@ -85,12 +86,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const u16* __restrict_
     for (int p = 0; p < NPL; ++p) {
 #pragma unroll
       for (int v = 0; v < AV; ++v) {
-        const int idx = tid + 256 * v, row = idx >> 2, kv = idx & 3;
+        const int idx = tid + NT * v, row = idx >> 2, kv = idx & 3;
         *reinterpret_cast<u32x4*>(&As[p][row * LDK + 8 * kv]) = ra[p * AV + v];
       }
 #pragma unroll
       for (int v = 0; v < BV; ++v) {
-        const int idx = tid + 256 * v, row = idx >> 2, kv = idx & 3;
+        const int idx = tid + NT * v, row = idx >> 2, kv = idx & 3;
         *reinterpret_cast<u32x4*>(&Bs[p][row * LDK + 8 * kv]) = rb[p * BV + v];
       }
     }
@@ -118,10 +119,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const u16* __restrict_
       for (int p = 0; p < NPL; ++p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          a[p][i] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * (BM / 2) + 32 * i + r) * LDK + 16 * s + 8 * h]);
+          a[p][i] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * (BM / WM) + 32 * i + r) * LDK + 16 * s + 8 * h]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          b[p][j] = *reinterpret_cast<const bf16x8*>(&Bs[p][(wn * (BN / 2) + 32 * j + r) * LDK + 16 * s + 8 * h]);
+          b[p][j] = *reinterpret_cast<const bf16x8*>(&Bs[p][(wn * (BN / WN) + 32 * j + r) * LDK + 16 * s + 8 * h]);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -146,27 +147,27 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const u16* __restrict_
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = bm * BM + wm * (BM / 2) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int col = bn * BN + wn * (BN / 2) + 32 * j + r;
+        const int row = bm * BM + wm * (BM / WM) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int col = bn * BN + wn * (BN / WN) + 32 * j + r;
         C[(size_t)row * N + col] = acc[i][j][e];
       }
 }
 
-template <int BM, int BN, int NPROD>
+template <int BM, int BN, int NPROD, int WM = 2, int WN = 2>
 static void run(const char* name, const u16* dA, const u16* dB, float* dC, int M, int N, int K, const float* hA, const float* hB,
                 const double* ref, const int* rows, int nrows) {
   if (M % BM || N % BN) return;  // conv-like shapes: only the tiles that divide
   const dim3 grid((M / BM) * (N / BN));
   const size_t lds = (size_t)(NPROD == 6 ? 3 : 2) * (BM + BN) * LDK * sizeof(u16);
-  CHECK(hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<BM, BN, NPROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, NPROD>), grid, dim3(256), lds, 0, dA, dB, dC, M, N, K);
+  CHECK(hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<BM, BN, NPROD, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, NPROD, WM, WN>), grid, dim3(64 * WM * WN), lds, 0, dA, dB, dC, M, N, K);
   CHECK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   const int iters = 20;
   CHECK(hipEventRecord(e0));
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, NPROD>), grid, dim3(256), lds, 0, dA, dB, dC, M, N, K);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, NPROD, WM, WN>), grid, dim3(64 * WM * WN), lds, 0, dA, dB, dC, M, N, K);
   CHECK(hipEventRecord(e1));
   CHECK(hipEventSynchronize(e1));
   float ms;
@@ -234,6 +235,10 @@ int main(int argc, char** argv) {
   run<128, 128, 6>("bf16x3, 6 products, 128x128", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
   run<256, 128, 6>("bf16x3, 6 products, 256x128", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
   run<256, 256, 6>("bf16x3, 6 products, 256x256", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<256, 256, 6, 2, 4>("bf16x3, 6 prod, 256x256 8w 2x4", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<256, 256, 6, 4, 2>("bf16x3, 6 prod, 256x256 8w 4x2", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<256, 128, 6, 4, 2>("bf16x3, 6 prod, 256x128 8w 4x2", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<128, 128, 6, 2, 4>("bf16x3, 6 prod, 128x128 8w 2x4", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
   run<128, 128, 3>("bf16x2, 3 products, 128x128", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
   run<256, 256, 3>("bf16x2, 3 products, 256x256", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
   return 0;
