@@ -5,6 +5,9 @@
 // against an fp64 reference on sampled rows, next to a plain fp32 FMA-chain result of the same rows (what a
 // v_mfma_f32_32x32x2_f32 kernel produces up to summation order).
 //
+// SPLITA variants take A as plain fp32 and split it in the loader (global fp32 -> registers -> three bf16 planes in LDS):
+// what a conv kernel would do to keep fp32 activations in HBM; B (the weights) stays pre-split.
+//
 // Both operands are K-contiguous ([M][K] and [N][K]).  Block tile BM x BN, 4 waves (2 x 2), BK = 32 (two 16-deep MFMA
 // steps), one LDS stage with the next tile's global loads in flight during the MFMAs.
 #include <hip/hip_runtime.h>
@@ -16,6 +19,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;
 constexpr int LDK = BK + 8;  // row pitch in bf16: 80 bytes, keeps the 16-byte fragment reads of 8 rows on distinct banks
 
@@ -48,8 +53,8 @@ __global__ void split3_kernel(const float* __restrict__ x, u16* __restrict__ pla
   planes[2 * n + i] = bf16_rn(r2);
 }
 
-template <int BM, int BN, int NPROD, int WM = 2, int WN = 2>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16x3_kernel(const u16* __restrict__ A, const u16* __restrict__ B, float* __restrict__ C,
+template <int BM, int BN, int NPROD, int WM = 2, int WN = 2, bool SPLITA = false>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16x3_kernel(const float* __restrict__ A32, const u16* __restrict__ A, const u16* __restrict__ B, float* __restrict__ C,
                                                            int M, int N, int K) {
   constexpr int NT = 64 * WM * WN;                        // threads
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;     // 32x32 tiles per wave in each direction
@@ -65,14 +70,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16x3_kernel(const u16* __
   const size_t planeA = (size_t)M * K, planeB = (size_t)N * K;
   const int r = lane & 31, h = lane >> 5;
 
+  constexpr int AV32 = BM * BK / 4 / NT;                  // float4 vectors per thread when A arrives as fp32
   u32x4 ra[NPL * AV], rb[NPL * BV];
+  f32x4 ra32[AV32];
   auto gload = [&](int kt) __attribute__((always_inline)) {
+    if (SPLITA) {
+#pragma unroll
+      for (int v = 0; v < AV32; ++v) {
+        const int idx = tid + NT * v, row = idx >> 3, kq = idx & 7;
+        ra32[v] = *reinterpret_cast<const f32x4*>(A32 + (size_t)(bm * BM + row) * K + kt * BK + 4 * kq);
+      }
+    }
 #pragma unroll
     for (int p = 0; p < NPL; ++p) {
+      if (!SPLITA) {
 #pragma unroll
-      for (int v = 0; v < AV; ++v) {
-        const int idx = tid + NT * v, row = idx >> 2, kv = idx & 3;
-        ra[p * AV + v] = *reinterpret_cast<const u32x4*>(A + p * planeA + (size_t)(bm * BM + row) * K + kt * BK + 8 * kv);
+        for (int v = 0; v < AV; ++v) {
+          const int idx = tid + NT * v, row = idx >> 2, kv = idx & 3;
+          ra[p * AV + v] = *reinterpret_cast<const u32x4*>(A + p * planeA + (size_t)(bm * BM + row) * K + kt * BK + 8 * kv);
+        }
       }
 #pragma unroll
       for (int v = 0; v < BV; ++v) {
@@ -82,12 +98,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16x3_kernel(const u16* __
     }
   };
   auto sstore = [&]() __attribute__((always_inline)) {
+    if (SPLITA) {  // hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid): v_cvt_pk_bf16_f32 and subtractions
+#pragma unroll
+      for (int v = 0; v < AV32; ++v) {
+        const int idx = tid + NT * v, row = idx >> 3, kq = idx & 7;
+        const f32x4 a = ra32[v];
+        const bf16x4 hi = __builtin_convertvector(a, bf16x4);
+        const f32x4 r1 = a - __builtin_convertvector(hi, f32x4);
+        const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
+        *reinterpret_cast<bf16x4*>(&As[0][row * LDK + 4 * kq]) = hi;
+        *reinterpret_cast<bf16x4*>(&As[1][row * LDK + 4 * kq]) = mid;
+        if (NPL == 3) {
+          const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
+          *reinterpret_cast<bf16x4*>(&As[2][row * LDK + 4 * kq]) = __builtin_convertvector(r2, bf16x4);
+        }
+      }
+    }
 #pragma unroll
     for (int p = 0; p < NPL; ++p) {
+      if (!SPLITA) {
 #pragma unroll
-      for (int v = 0; v < AV; ++v) {
-        const int idx = tid + NT * v, row = idx >> 2, kv = idx & 3;
-        *reinterpret_cast<u32x4*>(&As[p][row * LDK + 8 * kv]) = ra[p * AV + v];
+        for (int v = 0; v < AV; ++v) {
+          const int idx = tid + NT * v, row = idx >> 2, kv = idx & 3;
+          *reinterpret_cast<u32x4*>(&As[p][row * LDK + 8 * kv]) = ra[p * AV + v];
+        }
       }
 #pragma unroll
       for (int v = 0; v < BV; ++v) {
@@ -153,21 +187,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16x3_kernel(const u16* __
       }
 }
 
-template <int BM, int BN, int NPROD, int WM = 2, int WN = 2>
-static void run(const char* name, const u16* dA, const u16* dB, float* dC, int M, int N, int K, const float* hA, const float* hB,
+template <int BM, int BN, int NPROD, int WM = 2, int WN = 2, bool SPLITA = false>
+static void run(const char* name, const float* dA32, const u16* dA, const u16* dB, float* dC, int M, int N, int K, const float* hA, const float* hB,
                 const double* ref, const int* rows, int nrows) {
   if (M % BM || N % BN) return;  // conv-like shapes: only the tiles that divide
   const dim3 grid((M / BM) * (N / BN));
   const size_t lds = (size_t)(NPROD == 6 ? 3 : 2) * (BM + BN) * LDK * sizeof(u16);
-  CHECK(hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<BM, BN, NPROD, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, NPROD, WM, WN>), grid, dim3(64 * WM * WN), lds, 0, dA, dB, dC, M, N, K);
+  CHECK(hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<BM, BN, NPROD, WM, WN, SPLITA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, NPROD, WM, WN, SPLITA>), grid, dim3(64 * WM * WN), lds, 0, dA32, dA, dB, dC, M, N, K);
   CHECK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   const int iters = 20;
   CHECK(hipEventRecord(e0));
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, NPROD, WM, WN>), grid, dim3(64 * WM * WN), lds, 0, dA, dB, dC, M, N, K);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, NPROD, WM, WN, SPLITA>), grid, dim3(64 * WM * WN), lds, 0, dA32, dA, dB, dC, M, N, K);
   CHECK(hipEventRecord(e1));
   CHECK(hipEventSynchronize(e1));
   float ms;
@@ -232,14 +266,18 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(split3_kernel, dim3((unsigned)(((size_t)M * K + 255) / 256)), dim3(256), 0, 0, dA32, dA, (size_t)M * K);
   hipLaunchKernelGGL(split3_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, 0, dB32, dB, (size_t)N * K);
   CHECK(hipDeviceSynchronize());
-  run<128, 128, 6>("bf16x3, 6 products, 128x128", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
-  run<256, 128, 6>("bf16x3, 6 products, 256x128", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
-  run<256, 256, 6>("bf16x3, 6 products, 256x256", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
-  run<256, 256, 6, 2, 4>("bf16x3, 6 prod, 256x256 8w 2x4", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
-  run<256, 256, 6, 4, 2>("bf16x3, 6 prod, 256x256 8w 4x2", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
-  run<256, 128, 6, 4, 2>("bf16x3, 6 prod, 256x128 8w 4x2", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
-  run<128, 128, 6, 2, 4>("bf16x3, 6 prod, 128x128 8w 2x4", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
-  run<128, 128, 3>("bf16x2, 3 products, 128x128", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
-  run<256, 256, 3>("bf16x2, 3 products, 256x256", dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<128, 128, 6>("bf16x3, 6 products, 128x128", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<256, 128, 6>("bf16x3, 6 products, 256x128", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<256, 256, 6>("bf16x3, 6 products, 256x256", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<256, 256, 6, 2, 4>("bf16x3, 6 prod, 256x256 8w 2x4", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<256, 256, 6, 4, 2>("bf16x3, 6 prod, 256x256 8w 4x2", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<256, 128, 6, 4, 2>("bf16x3, 6 prod, 256x128 8w 4x2", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<128, 128, 6, 2, 4>("bf16x3, 6 prod, 128x128 8w 2x4", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<128, 128, 6, 2, 2, true>("6 prod, 128x128, A split in loader", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<128, 128, 6, 2, 4, true>("6 prod, 128x128 8w, A split", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<256, 256, 6, 2, 4, true>("6 prod, 256x256 8w, A split", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<256, 128, 6, 4, 2, true>("6 prod, 256x128 8w, A split", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<128, 128, 3>("bf16x2, 3 products, 128x128", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
+  run<256, 256, 3>("bf16x2, 3 products, 256x256", dA32, dA, dB, dC, M, N, K, hA, hB, ref, rows, nrows);
   return 0;
 }
