@@ -632,6 +632,164 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_kernel(const float* __restr
   fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
 }
 
+// ---- experimental: fp32 products from bf16 pieces -------------------------------------------------
+// Same implicit GEMM, loader, work planner and epilogue as conv_fprop_kernel; only the K loop differs: every fp32 operand
+// value is split in registers into three round-to-nearest bf16 pieces (hi + mid + lo = 24 significand bits), the pieces go
+// to LDS as k-contiguous rows, and each 16-deep step accumulates the six piece products of relative weight >= 2^-16 with
+// v_mfma_f32_32x32x16_bf16 (smallest first).  The dropped products are below 2^-24 relative, the order of fp32 rounding.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int X3_LDK = BK + 8;  // bf16 per LDS row: 80 bytes, the 16-byte fragment reads of 16 lanes cover all banks once
+
+// thread (row = tid / 8 + 32 p, k = 4 (tid % 8) .. + 3) -> planes[0 | 1 | 2][row][k]
+template <int ROWS, int P>
+__device__ __forceinline__ void store_split3(unsigned short* __restrict__ dst, const float4 (&v)[P], int tid) {
+  const int arow = tid >> 3, kg = tid & 7;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const f32x4_t a = {v[p].x, v[p].y, v[p].z, v[p].w};
+    const bf16x4_t hi = __builtin_convertvector(a, bf16x4_t);
+    const f32x4_t r1 = a - __builtin_convertvector(hi, f32x4_t);
+    const bf16x4_t mid = __builtin_convertvector(r1, bf16x4_t);
+    const f32x4_t r2 = r1 - __builtin_convertvector(mid, f32x4_t);
+    const bf16x4_t lo = __builtin_convertvector(r2, bf16x4_t);
+    unsigned short* q = dst + (arow + 32 * p) * X3_LDK + 4 * kg;
+    *reinterpret_cast<bf16x4_t*>(q) = hi;
+    *reinterpret_cast<bf16x4_t*>(q + ROWS * X3_LDK) = mid;
+    *reinterpret_cast<bf16x4_t*>(q + 2 * ROWS * X3_LDK) = lo;
+  }
+}
+
+// lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8 h + 0..7] and B[k][col r] of a 16-deep step
+template <int TM, int TN, int MS, int NS, int ROWS_A, int ROWS_B>
+__device__ __forceinline__ void mma_stage_x3(const unsigned short* __restrict__ As, const unsigned short* __restrict__ Bs,
+                                             f32x16 (&acc)[TM][TN], int wm0, int wn0, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < BK / 16; ++s) {
+    bf16x8_t a[3][TM], b[3][TN];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[p][i] = *reinterpret_cast<const bf16x8_t*>(As + (p * ROWS_A + wm0 + MS * i + r) * X3_LDK + 16 * s + 8 * h);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[p][j] = *reinterpret_cast<const bf16x8_t*>(Bs + (p * ROWS_B + wn0 + NS * j + r) * X3_LDK + 16 * s + 8 * h);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+      }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_fprop_x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ y, Geom g, int NT, Work wk,
+                                                          float* __restrict__ slab, FpropEpi epi) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AP = BM / 32, BP = BN / 32;
+  static_assert(3 * (BM + BN) * X3_LDK * 2 >= WM * 32 * BN * 4, "the epilogue stages a tile pass in the same LDS");
+  __shared__ __attribute__((aligned(16))) unsigned short smem16[3 * (BM + BN) * X3_LDK];
+  unsigned short* const As = smem16;
+  unsigned short* const Bs = smem16 + 3 * BM * X3_LDK;
+  float* const smem = reinterpret_cast<float*>(smem16);
+
+  // Tile order: Cout-tile fastest, so the blocks that share an activation row-tile are consecutive and
+  // (through xcd_remap) land on one XCD / one L2.
+  const int nk = g.Ktot / BK;
+  const WorkItem it = get_work(blockIdx.x, wk, nk);
+  const int mt = it.tile / NT, nt = it.tile - mt * NT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;  // tile i / j of the wave: + 32*WM*i / + 32*WN*j
+  const int arow = tid >> 3, kg = tid & 7;
+  const int HoWo = g.Ho * g.Wo;
+  const int frame_bytes = g.H * g.W * g.Cin * 4;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * frame_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, g.Cout * g.Ktot * 4, 0x00020000);
+
+  int a_base[AP], a_t[AP], a_hi0[AP], a_wi0[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int m = mt * BM + arow + 32 * p;
+    const bool ok = m < g.M;
+    int n, rem, ho, wo;
+    fast_divmod(ok ? m : 0, HoWo, g.rcp_HoWo, n, rem);
+    fast_divmod(rem, g.Wo, g.rcp_Wo, ho, wo);
+    a_t[p] = n % g.T;
+    a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);  // rows past M fail every bounds test
+    a_wi0[p] = wo * g.stride - g.pad;
+    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad) * g.Cin * 4 + 16 * kg;
+  }
+  int b_base[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) b_base[p] = ((nt * BN + arow + 32 * p) * g.Ktot + 4 * kg) * 4;
+
+  // K index state (uniform): K-step kt = chunk * R*S + r * S + s
+  const int RS = g.R * g.S;
+  int chunk = it.kb / RS, r, s;
+  {
+    const int tap = it.kb - chunk * RS;
+    r = tap / g.S;
+    s = tap - r * g.S;
+  }
+
+  float4 ra[AP], rb[BP];
+  auto load = [&]() {
+    const int cls = shift_class(chunk * BK + 4 * kg, g.fold);
+    const int koff_a = ((r * g.W + s) * g.Cin + chunk * BK) * 4;
+    const int koff_b = ((r * g.S + s) * g.Cin + chunk * BK) * 4;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const bool v = (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W &&
+                     (unsigned)(a_t[p] + cls) < (unsigned)g.T;
+      // invalid lanes: set the top bit -> beyond num_records -> the load returns zeros
+      ra[p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB), 0);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p) rb[p] = buf_load16(wr, b_base[p], koff_b);
+    // advance to the next K-step (branch-free)
+    s += 1;
+    const int ws_ = (s == g.S) ? 1 : 0;
+    s = ws_ ? 0 : s;
+    r += ws_;
+    const int wr_ = (r == g.R) ? 1 : 0;
+    r = wr_ ? 0 : r;
+    chunk += wr_;
+  };
+
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+
+  load();
+  for (int kt = it.kb; kt < it.ke; ++kt) {
+    __syncthreads();  // everyone is done reading the previous stage
+    store_split3<BM, AP>(As, ra, tid);
+    store_split3<BN, BP>(Bs, rb, tid);
+    __syncthreads();
+    if (kt + 1 < it.ke) load();  // in flight during the MFMAs
+    mma_stage_x3<TM, TN, 32 * WM, 32 * WN, BM, BN>(As, Bs, acc, wm0, wn0, lane);
+  }
+
+  if (it.pslot >= 0) {
+    store_partial<TM, TN>(slab, it.pslot, acc, tid);
+    return;
+  }
+  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
+}
+
 // fprop for the stem (Cin = 4 on NHWC4): one filter tap per 16-byte load, K = R*S*4 padded to a multiple of 32
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -846,6 +1004,140 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
       __syncthreads();
       if (kt + 1 < it.ke) load();
       mma_stage<LDA, LDB, TM, TN, 32 * WM, 32 * WN, true, false>(As, Bs, acc, wm0, wn0, lane);
+    }
+  }
+  if (it.pslot >= 0) {
+    store_partial<TM, TN>(slab, it.pslot, acc, tid);
+    return;
+  }
+
+  // Epilogue.  Forward read xs[frame n] = x[frame n + cls]; so the gradient of row m goes to
+  // frame n + cls when that frame is inside the clip.  Rows whose target falls outside the clip
+  // ("orphans") instead write the zero that the unreachable frame at the other clip end needs,
+  // which makes the scatter a bijection over dx.
+  dgrad_epilogue<BM, BN, WM, WN>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
+    if (st == 1) return mrow;
+    const int n = mrow / HcWc;
+    const int rem = mrow - n * HcWc;
+    const int hc = rem / Wc;
+    return (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
+  });
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_dgrad_x3_kernel(const float* __restrict__ dy, const float* __restrict__ wt,
+                                                          float* __restrict__ dx, const float* __restrict__ add_src,
+                                                          const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk,
+                                                          float* __restrict__ slab, BnStat stat) {
+  // bf16-piece variant of conv_dgrad_kernel (see conv_fprop_x3_kernel).  wt = the weights transposed per tap,
+  // [R*S][Cin][Cout], so that the B operand is k-contiguous like dy.
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AP = BM / 32, BP = BN / 32;
+  static_assert(3 * (BM + BN) * X3_LDK * 2 >= WM * 32 * BN * 4, "the epilogue stages a tile pass in the same LDS");
+  __shared__ __attribute__((aligned(16))) unsigned short smem16[3 * (BM + BN) * X3_LDK];
+  unsigned short* const As = smem16;
+  unsigned short* const Bs = smem16 + 3 * BM * X3_LDK;
+  float* const smem = reinterpret_cast<float*>(smem16);
+
+  // parity class of the input pixel (stride 1: a single class)
+  const int st = g.stride;
+  const int ph = blockIdx.y / st, pw = blockIdx.y - ph * st;
+  const int Hc = (g.H - ph + st - 1) / st, Wc = (g.W - pw + st - 1) / st;
+  const int Mc = g.N * Hc * Wc;
+  const int MT = (Mc + BM - 1) / BM;
+  const int r0 = (ph + g.pad) % st, s0 = (pw + g.pad) % st;
+  const int nr = r0 < g.R ? (g.R - r0 + st - 1) / st : 0;
+  const int ns = s0 < g.S ? (g.S - s0 + st - 1) / st : 0;
+  const int bh = (ph + g.pad - r0) / st, bw = (pw + g.pad - s0) / st;
+  const int ntap = nr * ns;
+  const int nk = ntap * g.Cout / BK;  // 0 for a class no filter tap reaches (e.g. 1x1 stride 2, odd pixels)
+
+  int mt, nt;
+  WorkItem it;
+  if (st == 1) {
+    it = get_work(blockIdx.x, wk, nk);
+    mt = it.tile / NT;
+    nt = it.tile - mt * NT;
+  } else {  // parity classes have different sizes: padded grid, no K split
+    const int id = blockIdx.x;
+    const int xcd = id & 7, jj = id >> 3;
+    mt = (jj / NT) * 8 + xcd;
+    nt = jj % NT;
+    if (mt >= MT) return;
+    it.tile = 0;
+    it.kb = 0;
+    it.ke = nk;
+    it.pslot = -1;
+  }
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;  // tile i / j of the wave: + 32*WM*i / + 32*WN*j
+  const int arow = tid >> 3, kg = tid & 7;
+  const int HcWc = Hc * Wc;
+  const int RS = g.R * g.S;
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.N * g.Ho * g.Wo * g.Cout * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, g.Cout * RS * g.Cin * 4, 0x00020000);
+
+  int a_base[AP], a_h[AP], a_w[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int m = mt * BM + arow + 32 * p;
+    const bool ok = m < Mc;
+    const int mm = ok ? m : 0;
+    const int n = mm / HcWc;
+    const int rem = mm - n * HcWc;
+    const int hc = rem / Wc, wc = rem - hc * Wc;
+    a_h[p] = ok ? hc + bh : -(1 << 20);
+    a_w[p] = wc + bw;
+    a_base[p] = ((n * g.Ho + hc + bh) * g.Wo + wc + bw) * g.Cout * 4 + 16 * kg;
+  }
+  // transposed weights: row ci = nt*BN + arow + 32p of tap `tap`, 4 consecutive co: (tap * Cin + ci) * Cout + co0 + 4*kg
+  int b_base[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) b_base[p] = ((nt * BN + arow + 32 * p) * g.Cout + 4 * kg) * 4;
+
+  // K index state (uniform): kt = chunk * ntap + ir * ns + is  (tap-fastest)
+  int chunk = ntap > 0 ? it.kb / ntap : 0, ir, is;
+  {
+    const int ct = ntap > 0 ? it.kb - chunk * ntap : 0;
+    ir = ns > 0 ? ct / ns : 0;
+    is = ct - ir * ns;
+  }
+
+  float4 ra[AP], rb[BP];
+  auto load = [&]() {
+    const int tap = (r0 + ir * st) * g.S + (s0 + is * st);
+    const int koff_a = (chunk * BK - (ir * g.Wo + is) * g.Cout) * 4;
+    const int koff_b = (tap * g.Cin * g.Cout + chunk * BK) * 4;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const bool v = (unsigned)(a_h[p] - ir) < (unsigned)g.Ho && (unsigned)(a_w[p] - is) < (unsigned)g.Wo;
+      ra[p] = buf_load16(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB), 0);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p) rb[p] = buf_load16(wr, b_base[p], koff_b);
+    is += 1;
+    const int w1 = (is == ns) ? 1 : 0;
+    is = w1 ? 0 : is;
+    ir += w1;
+    const int w2 = (ir == nr) ? 1 : 0;
+    ir = w2 ? 0 : ir;
+    chunk += w2;
+  };
+
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+
+  if (it.ke > it.kb) {
+    load();
+    for (int kt = it.kb; kt < it.ke; ++kt) {
+      __syncthreads();
+      store_split3<BM, AP>(As, ra, tid);
+      store_split3<BN, BP>(Bs, rb, tid);
+      __syncthreads();
+      if (kt + 1 < it.ke) load();
+      mma_stage_x3<TM, TN, 32 * WM, 32 * WN, BM, BN>(As, Bs, acc, wm0, wn0, lane);
     }
   }
   if (it.pslot >= 0) {
@@ -1182,8 +1474,8 @@ bool debug_plan() {
 // Cost model (us): one 32-deep K-iteration of a 64-accumulator block = `iter_us` of its CU's matrix pipes; a CU
 // holding 1 / 2 / 3 blocks reaches ~60 / 92 / 100 % of that rate; the fix-up costs ~10 us + 2.5 us per slice + its
 // bytes at ~8 TB/s.
-Work plan_work(int tiles, int nk, double iter_us, size_t seg_bytes, size_t ws_bytes) {
-  const int cus = 256, W = 3 * cus;
+Work plan_work(int tiles, int nk, double iter_us, size_t seg_bytes, size_t ws_bytes, int per_cu = 3) {
+  const int cus = 256, W = per_cu * cus;
   Work wk;
   const int q = tiles / W, r = tiles - q * W;
   wk.dp_tiles = tiles;
@@ -1225,7 +1517,7 @@ struct FdPlan {
   Work wk;
 };
 
-FdPlan plan_fprop(const Geom& g, size_t ws_bytes) {
+FdPlan plan_fprop(const Geom& g, size_t ws_bytes, bool x3 = false) {
   FdPlan p;
   p.wide = (g.Cout % 128) == 0;
   const int bn = p.wide ? 128 : 64;
@@ -1238,12 +1530,14 @@ FdPlan plan_fprop(const Geom& g, size_t ws_bytes) {
     p.wk.rem_tiles = 0;
     p.wk.split = 1;
   } else {
-    p.wk = plan_work(p.MT * p.NT, p.nk, p.wide ? 1.7 : 0.85, p.seg_bytes, ws_bytes);
+    // the bf16-piece kernel: two blocks per CU (60 KB of LDS each), a K-iteration of 48 bf16 MFMAs instead of 64 fp32 ones
+    p.wk = (x3 && p.wide) ? plan_work(p.MT * p.NT, p.nk, 0.9, p.seg_bytes, ws_bytes, 2)
+                          : plan_work(p.MT * p.NT, p.nk, p.wide ? 1.7 : 0.85, p.seg_bytes, ws_bytes);
   }
   return p;
 }
 
-FdPlan plan_dgrad(const Geom& g, size_t ws_bytes) {
+FdPlan plan_dgrad(const Geom& g, size_t ws_bytes, bool x3 = false) {
   FdPlan p;
   p.wide = (g.Cin % 128) == 0;
   const int bn = p.wide ? 128 : 64;
@@ -1254,7 +1548,8 @@ FdPlan plan_dgrad(const Geom& g, size_t ws_bytes) {
   p.nk = g.R * g.S * g.Cout / BK;
   p.seg_bytes = (size_t)(p.wide ? 64 : 32) * 256 * sizeof(float);
   if (st == 1) {
-    p.wk = plan_work(p.MT * p.NT, p.nk, p.wide ? 1.7 : 0.85, p.seg_bytes, ws_bytes);
+    p.wk = (x3 && p.wide) ? plan_work(p.MT * p.NT, p.nk, 0.9, p.seg_bytes, ws_bytes, 2)
+                          : plan_work(p.MT * p.NT, p.nk, p.wide ? 1.7 : 0.85, p.seg_bytes, ws_bytes);
   } else {
     p.wk.dp_tiles = ((p.MT + 7) / 8) * 8 * p.NT;  // padded grid per parity class
     p.wk.rem_tiles = 0;
@@ -1336,8 +1631,9 @@ extern "C" int bdv_conv_fprop_stat_rows(const bdv_conv_geom* gg) {
   return (int)((M + 127) / 128);
 }
 
-extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* gg, float* bn_partial,
-                              const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+int conv_fprop_impl(const float* x, const float* w, float* y, const bdv_conv_geom* gg, float* bn_partial,
+                    const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream, bool x3) {
   if (int e = check_geom(gg, "bdv_conv_fprop")) return e;
   BDV_REQUIRE(x && w && y, "bdv_conv_fprop: null pointer");
   FpropEpi epi = {bn_partial, 0, nullptr, nullptr, nullptr, 0};
@@ -1358,7 +1654,7 @@ extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bd
   g.Ktot = g.R * g.S * g.Cin;
   hipStream_t s = (hipStream_t)stream;
   const bool c4 = (g.Cin % BK) != 0;
-  const FdPlan p = plan_fprop(g, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0);
+  const FdPlan p = plan_fprop(g, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, x3 && !c4);
   const int blocks = p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split;
   epi.MT = p.MT;
   float* slab = (float*)workspace;
@@ -1370,6 +1666,8 @@ extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bd
       hipLaunchKernelGGL((conv_fprop_c4_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, epi);
     else
       hipLaunchKernelGGL((conv_fprop_c4_kernel<128, 64, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, epi);
+  } else if (p.wide && x3) {
+    hipLaunchKernelGGL((conv_fprop_x3_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, epi);
   } else if (p.wide) {
     hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, epi);
   } else {
@@ -1386,6 +1684,17 @@ extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bd
   }
   return BDV_OK;
 }
+}  // namespace
+
+extern "C" int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* gg, float* bn_partial,
+                              const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream) {
+  return conv_fprop_impl(x, w, y, gg, bn_partial, affine, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int bdv_conv_fprop_x3(const float* x, const float* w, float* y, const bdv_conv_geom* gg, float* bn_partial,
+                                 const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream) {
+  return conv_fprop_impl(x, w, y, gg, bn_partial, affine, workspace, workspace_bytes, stream, true);
+}
 
 extern "C" int bdv_conv_dgrad_stat_rows(const bdv_conv_geom* gg) {
   if (check_geom(gg, "bdv_conv_dgrad_stat_rows")) return 0;
@@ -1393,9 +1702,11 @@ extern "C" int bdv_conv_dgrad_stat_rows(const bdv_conv_geom* gg) {
   return (int)((M + 127) / 128);
 }
 
-extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const float* add_src,
-                              const uint32_t* add_mask_src, const bdv_conv_geom* gg, const bdv_bn_stat_fuse* bn_stat,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+// w_t != nullptr: the bf16-piece kernel on the per-tap transposed weights (wide tiles only), else the fp32-MFMA kernels
+int conv_dgrad_impl(const float* dy, const float* w, const float* w_t, float* dx, const float* add_src,
+                    const uint32_t* add_mask_src, const bdv_conv_geom* gg, const bdv_bn_stat_fuse* bn_stat, void* workspace,
+                    size_t workspace_bytes, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_dgrad")) return e;
   BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   if (bn_stat != nullptr) {
@@ -1421,13 +1732,17 @@ extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const 
   g.Ktot = g.R * g.S * g.Cout;
   hipStream_t s = (hipStream_t)stream;
   const int st = g.stride;
-  const FdPlan p = plan_dgrad(g, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0);
+  const bool x3 = w_t != nullptr && (g.Cin % 128) == 0;
+  BDV_REQUIRE(w_t == nullptr || bdv_aligned16(w_t), "bdv_conv_dgrad_x3: w_t must be 16-byte aligned");
+  const FdPlan p = plan_dgrad(g, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, x3);
   const dim3 grid(p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split, st * st);
   float* slab = (float*)workspace;
   if (debug_plan())
     fprintf(stderr, "[bdv plan] dgrad %dx%d Cin %d Cout %d k%d s%d: tiles %d nk %d -> dp %d rem %d split %d\n", g.H, g.W,
             g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
-  if (p.wide)
+  if (p.wide && x3)
+    hipLaunchKernelGGL((conv_dgrad_x3_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, dy, w_t, dx, add_src, add_mask_src, g, p.NT, p.wk, slab, stat);
+  else if (p.wide)
     hipLaunchKernelGGL((conv_dgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, p.NT, p.wk, slab, stat);
   else
     hipLaunchKernelGGL((conv_dgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, p.NT, p.wk, slab, stat);
@@ -1441,6 +1756,20 @@ extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const 
     BDV_LAUNCH_CHECK("bdv_conv_dgrad(fixup)");
   }
   return BDV_OK;
+}
+}  // namespace
+
+extern "C" int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const float* add_src,
+                              const uint32_t* add_mask_src, const bdv_conv_geom* gg, const bdv_bn_stat_fuse* bn_stat,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  return conv_dgrad_impl(dy, w, nullptr, dx, add_src, add_mask_src, gg, bn_stat, workspace, workspace_bytes, stream);
+}
+
+extern "C" int bdv_conv_dgrad_x3(const float* dy, const float* w, const float* w_t, float* dx, const float* add_src,
+                                 const uint32_t* add_mask_src, const bdv_conv_geom* gg, const bdv_bn_stat_fuse* bn_stat,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  BDV_REQUIRE(w_t != nullptr, "bdv_conv_dgrad_x3: w_t is null");
+  return conv_dgrad_impl(dy, w, w_t, dx, add_src, add_mask_src, gg, bn_stat, workspace, workspace_bytes, stream);
 }
 
 namespace {

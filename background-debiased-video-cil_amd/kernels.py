@@ -64,8 +64,14 @@ def _conv_ws(g: ConvGeom, kind: int, device, tag: str) -> torch.Tensor:
     return workspace(need, device, tag)
 
 
+import os as _os
+
+# EXPERIMENTAL: forward convolutions with fp32 products formed from bf16 pieces (bdv_conv_fprop_x3)
+FPROP_X3 = _os.environ.get('BDVCIL_FPROP_X3', '0') != '0'
+
+
 def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torch.Tensor] = None,
-               ws_tag: str = 'conv', bn_stats: bool = False, affine=None):
+               ws_tag: str = 'conv', bn_stats: bool = False, affine=None, x3: Optional[bool] = None):
     """x (N,H,W,Cin) NHWC, w (Cout,R,S,Cin) -> y (N,Ho,Wo,Cout); with bn_stats also the fused BatchNorm partial
     sums (float[2][rows][Cout]) for ``bn_train_finalize``.
     ``affine = (scale, shift, residual | None, relu)``: eval-mode BatchNorm folded into the epilogue,
@@ -90,14 +96,18 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
         if res is not None:
             _chk(res, (g.N, g.Ho, g.Wo, g.Cout), name='residual')
         aff = ConvAffine(scale.data_ptr(), shift.data_ptr(), res.data_ptr() if res is not None else None, int(bool(relu)))
-    check(lib().bdv_conv_fprop(_p(x), _p(w), _p(y), ctypes.byref(g), _p(part), ctypes.byref(aff) if aff is not None else None,
-                               _p(ws), ws.numel(), _stream()), 'bdv_conv_fprop')
+    fn = lib().bdv_conv_fprop_x3 if (FPROP_X3 if x3 is None else x3) else lib().bdv_conv_fprop
+    check(fn(_p(x), _p(w), _p(y), ctypes.byref(g), _p(part), ctypes.byref(aff) if aff is not None else None,
+             _p(ws), ws.numel(), _stream()), 'bdv_conv_fprop')
     return (y, part) if bn_stats else y
+
+
+DGRAD_X3 = _os.environ.get('BDVCIL_DGRAD_X3', '0') != '0'     # EXPERIMENTAL, like FPROP_X3
 
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional[torch.Tensor] = None,
                add_mask_src: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-               ws_tag: str = 'conv', bn_stats=None):
+               ws_tag: str = 'conv', bn_stats=None, x3: Optional[bool] = None):
     """``bn_stats = (y, relu_mask | None, mean, invstd)`` of the conv unit whose output gradient this dgrad produces:
     the BatchNorm-backward statistics are then taken in the epilogue and ``(dx, partial)`` is returned; pass ``partial``
     to ``bn_backward(stat_partial=...)``.  Needs stride 1 and no temporal shift."""
@@ -124,6 +134,12 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
         fuse = BnStatFuse(y.data_ptr(), mask.data_ptr() if mask is not None else None, mean.data_ptr(), invstd.data_ptr(),
                           partial.data_ptr())
     ws = _conv_ws(g, 1, dy.device, ws_tag)
+    if (DGRAD_X3 if x3 is None else x3) and g.Cin % 128 == 0:
+        w_t = w.permute(1, 2, 3, 0).contiguous()            # (R, S, Cin, Cout): contraction index contiguous
+        check(lib().bdv_conv_dgrad_x3(_p(dy), _p(w), _p(w_t), _p(dx), _p(add_src), _p(add_mask_src), ctypes.byref(g),
+                                      ctypes.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), _stream()),
+              'bdv_conv_dgrad_x3')
+        return dx if bn_stats is None else (dx, partial)
     check(lib().bdv_conv_dgrad(_p(dy), _p(w), _p(dx), _p(add_src), _p(add_mask_src), ctypes.byref(g),
                                ctypes.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), _stream()), 'bdv_conv_dgrad')
     return dx if bn_stats is None else (dx, partial)

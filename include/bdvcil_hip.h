@@ -72,6 +72,13 @@ typedef struct bdv_conv_affine {
 } bdv_conv_affine;
 int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* g, float* bn_partial,
                    const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream);
+/* EXPERIMENTAL (off by default in the Python layer, BDVCIL_FPROP_X3=1): the same convolution with every fp32 product formed
+ * from bf16 pieces -- each operand value is split in the loader into three round-to-nearest bf16 terms and six
+ * v_mfma_f32_32x32x16_bf16 products per K-step are accumulated in fp32 (error of the order of fp32
+ * rounding).  Same arguments, workspace and epilogues as bdv_conv_fprop; used for Cout % 128 == 0 and Cin % 32 == 0,
+ * other shapes run the fp32-MFMA kernels. */
+int bdv_conv_fprop_x3(const float* x, const float* w, float* y, const bdv_conv_geom* g, float* bn_partial,
+                      const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream);
 
 /* BatchNorm-backward statistics fused into dgrad: dx (the gradient w.r.t. the BN(+ReLU) output of the PREVIOUS conv unit,
  * whose saved conv output is y) is reduced in the dgrad epilogue to partial[0][r][c] = sum(g), partial[1][r][c] =
@@ -93,6 +100,12 @@ int bdv_conv_dgrad_stat_rows(const bdv_conv_geom* g);
 int bdv_conv_dgrad(const float* dy, const float* w, float* dx, const float* add_src,
                    const uint32_t* add_mask_src, const bdv_conv_geom* g, const bdv_bn_stat_fuse* bn_stat, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* EXPERIMENTAL counterpart of bdv_conv_fprop_x3 for the data gradient.  w_t = the weights transposed per filter tap,
+ * (R*S, Cin, Cout) contiguous, so that both operands are contiguous along the contraction; used when Cin % 128 == 0,
+ * other shapes run bdv_conv_dgrad's kernels on w. */
+int bdv_conv_dgrad_x3(const float* dy, const float* w, const float* w_t, float* dx, const float* add_src,
+                      const uint32_t* add_mask_src, const bdv_conv_geom* g, const bdv_bn_stat_fuse* bn_stat, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* wgrad: dw[Cout,R,S,Cin] = beta * dw + sum_pixels dy (x) shift(x).  Deterministic split-K:
  * partial slabs go to `workspace`, a second kernel reduces them in fixed order. */

@@ -112,6 +112,55 @@ def test_wgrad(case, dev):
     _close(dw2.cpu(), 2 * ref)
 
 
+@pytest.mark.parametrize('case', [c for c in CASES if c[4] % 128 == 0 and c[3] % 32 == 0])
+def test_fprop_from_bf16_pieces(case, dev):
+    """bdv_conv_fprop_x3 (experimental): fp32 products formed from three bf16 pieces per operand value.  Same tolerance as
+    the fp32-MFMA kernel against the CPU reference, and close to the fp32-MFMA result itself; fused statistics and the
+    folded eval-mode BatchNorm go through the same epilogues."""
+    from bdvcil_amd import kernels as K
+    N, H, W, Cin, Cout, R, st, pad, T, fold = case
+    x, w = _mk(case, 5)
+    ref = _ref(x, w, st, pad, T, fold).permute(0, 2, 3, 1)
+    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    y3, part3 = K.conv_fprop(xd, wd, g, bn_stats=True, x3=True)
+    y1, part1 = K.conv_fprop(xd, wd, g, bn_stats=True, x3=False)
+    _close(y3.cpu(), ref)
+    _close(y3.cpu(), y1.cpu(), tol=4e-6)
+    _close(part3.sum(1).cpu(), part1.sum(1).cpu(), tol=2e-5)
+    scale, shift = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
+    res = torch.randn_like(y1)
+    a3 = K.conv_fprop(xd, wd, g, affine=(scale, shift, res, True), x3=True)
+    a1 = K.conv_fprop(xd, wd, g, affine=(scale, shift, res, True), x3=False)
+    _close(a3.cpu(), a1.cpu(), tol=1e-5)
+    assert torch.equal(K.conv_fprop(xd, wd, g, x3=True), y3)          # deterministic
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[3] % 128 == 0])
+@pytest.mark.parametrize('with_add', [False, True])
+def test_dgrad_from_bf16_pieces(case, with_add, dev):
+    """bdv_conv_dgrad_x3 (experimental) against the CPU reference and the fp32-MFMA kernel, with the residual add, the
+    temporal un-shift and the stride-2 parity classes going through the unchanged epilogue."""
+    from bdvcil_amd import kernels as K
+    N, H, W, Cin, Cout, R, st, pad, T, fold = case
+    x, w = _mk(case, 7)
+    x.requires_grad_(True)
+    y = _ref(x, w, st, pad, T, fold)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(11))
+    y.backward(dy)
+    ref = x.grad.permute(0, 2, 3, 1)
+    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    add = torch.randn(ref.shape, generator=torch.Generator().manual_seed(12)) if with_add else None
+    d3 = K.conv_dgrad(dyd, wd, g, add_src=add.to(dev) if with_add else None, x3=True)
+    d1 = K.conv_dgrad(dyd, wd, g, add_src=add.to(dev) if with_add else None, x3=False)
+    _close(d3.cpu(), ref + add if with_add else ref)
+    _close(d3.cpu(), d1.cpu(), tol=4e-6)
+    assert torch.equal(K.conv_dgrad(dyd, wd, g, add_src=add.to(dev) if with_add else None, x3=True), d3)
+
+
 def test_wgrad_partial_and_batched_reduce(dev):
     """Weight gradients left as split-K partial products and reduced together in one launch (what a stage's backward does)
     equal the one-call form bit for bit, for a batch of layers of very different sizes."""
