@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _lib = None
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     'bdv_conv_wgrad': (c_int, [P, P, P, c_float, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_conv_wgrad_splits': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_wgrad_partial': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, P]),
+    'bdv_conv_wgrad_partial_x3': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_wgrad_reduce_batched': (c_int, [P, P, P, P, c_int, c_float, P]),
     'bdv_bn_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'bdv_bn_train_stats': (c_int, [P, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_size_t, P]),

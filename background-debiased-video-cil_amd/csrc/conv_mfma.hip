@@ -790,6 +790,78 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_x3_kernel(const float* __re
   fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
 }
 
+// wgrad variant of the bf16-piece loop: both operands arrive contiguous along channels, not along the contraction (pixels).
+// The three planes are stored k-major, [plane][32 k rows][COLS + 8] bf16 (8-byte stores, like the fp32 image), and a lane
+// gathers its 8 consecutive k values of one channel with 16-bit LDS reads (32 lanes read 64 contiguous bytes of a row:
+// conflict-free).  Eight times the LDS read instructions of the row-major image, still cheaper than fp32 MFMAs.
+template <int COLS>
+struct X3KMajor {
+  static constexpr int LDW = COLS + 8;         // bf16 per k row
+  static constexpr int PLANE = BK * LDW;       // bf16 per plane
+};
+
+template <int COLS, int PASSES>
+__device__ __forceinline__ void store_split3_kmajor(unsigned short* __restrict__ dst, const float4 (&v)[PASSES], int tid) {
+  constexpr int V = COLS / 4;
+  constexpr int LDW = X3KMajor<COLS>::LDW, PLANE = X3KMajor<COLS>::PLANE;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int idx = tid + 256 * p;
+    const int krow = idx / V, c4 = idx - krow * V;
+    const f32x4_t a = {v[p].x, v[p].y, v[p].z, v[p].w};
+    const bf16x4_t hi = __builtin_convertvector(a, bf16x4_t);
+    const f32x4_t r1 = a - __builtin_convertvector(hi, f32x4_t);
+    const bf16x4_t mid = __builtin_convertvector(r1, bf16x4_t);
+    const f32x4_t r2 = r1 - __builtin_convertvector(mid, f32x4_t);
+    const bf16x4_t lo = __builtin_convertvector(r2, bf16x4_t);
+    unsigned short* q = dst + krow * LDW + 4 * c4;
+    *reinterpret_cast<bf16x4_t*>(q) = hi;
+    *reinterpret_cast<bf16x4_t*>(q + PLANE) = mid;
+    *reinterpret_cast<bf16x4_t*>(q + 2 * PLANE) = lo;
+  }
+}
+
+template <int TM, int TN, int MS, int NS, int COLS_A, int COLS_B>
+__device__ __forceinline__ void mma_stage_x3_kmajor(const unsigned short* __restrict__ As, const unsigned short* __restrict__ Bs,
+                                                    f32x16 (&acc)[TM][TN], int wm0, int wn0, int lane) {
+  constexpr int LDA = X3KMajor<COLS_A>::LDW, PA = X3KMajor<COLS_A>::PLANE;
+  constexpr int LDB = X3KMajor<COLS_B>::LDW, PB = X3KMajor<COLS_B>::PLANE;
+  typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < BK / 16; ++s) {
+    bf16x8_t a[3][TM], b[3][TN];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        u16x8_t f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = As[p * PA + (16 * s + 8 * h + e) * LDA + wm0 + MS * i + r];
+        a[p][i] = __builtin_bit_cast(bf16x8_t, f);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        u16x8_t f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = Bs[p * PB + (16 * s + 8 * h + e) * LDB + wn0 + NS * j + r];
+        b[p][j] = __builtin_bit_cast(bf16x8_t, f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+      }
+  }
+}
+
 // fprop for the stem (Cin = 4 on NHWC4): one filter tap per 16-byte load, K = R*S*4 padded to a multiple of 32
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -1361,6 +1433,180 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
   }
 }
 
+template <int BM, int BN, int WM, int WN, bool C4, bool INCR>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          float* __restrict__ slab, Geom g, int MTw, int NTw,
+                                                          int kt_per_split) {
+  // bf16-piece variant of conv_wgrad_kernel (see conv_fprop_x3_kernel / mma_stage_x3_kmajor)
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AP = BM / 32, BP = BN / 32;
+  constexpr int AV = BM / 4, BV = BN / 4;
+  __shared__ __attribute__((aligned(16))) unsigned short smem16[3 * (X3KMajor<BM>::PLANE + X3KMajor<BN>::PLANE)];
+  unsigned short* const As = smem16;
+  unsigned short* const Bs = smem16 + 3 * X3KMajor<BM>::PLANE;
+
+  // All tiles of one K slice read the same rows of dy and (up to the filter halo) of x.  Work index w = slice * tiles + tile,
+  // handed out so that one XCD gets a contiguous range of w: the tiles of a slice then run at the same time behind the
+  // same L2 and each operand row is fetched from the fabric about once instead of once per tile (measured before the
+  // remap: 0.77 GB fetched per launch of the 128x128 kernel, 2-4 GB for the 64-channel layers and the stem).
+  const int tiles = MTw * NTw;
+  const int wi = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = wi / tiles;
+  const int tile = wi - split * tiles;
+  const int mt = tile % MTw, nt = tile / MTw;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;  // tile i / j of the wave: + 32*WM*i / + 32*WN*j
+  const int HoWo = g.Ho * g.Wo;
+  const int frame_bytes = g.H * g.W * g.Cin * 4;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * frame_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.M * g.Cout * 4, 0x00020000);
+
+  // A: dy rows m0 + krow, columns mt*BM + 4*c4
+  int a_off[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int idx = tid + 256 * p;
+    const int krow = idx / AV, c4 = idx - krow * AV;
+    a_off[p] = (krow * g.Cout + mt * BM + 4 * c4) * 4;
+  }
+  // B: column -> (tap, ci) for this thread's loads (fixed over the K loop)
+  int b_krow[BP], b_off[BP], b_r[BP], b_s[BP], b_cls[BP];
+  bool b_cok[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) {
+    const int idx = tid + 256 * p;
+    const int krow = idx / BV, c4 = idx - krow * BV;
+    b_krow[p] = krow;
+    int tap, ci;
+    if (C4) {
+      const int ncol = nt * BN + 4 * c4;
+      tap = ncol / g.Cin;
+      ci = ncol - tap * g.Cin;
+      b_cok[p] = ncol < g.Ktot;
+    } else {
+      const int per_tap = g.Cin / BN;
+      tap = nt / per_tap;
+      ci = (nt - tap * per_tap) * BN + 4 * c4;
+      b_cok[p] = true;
+    }
+    b_r[p] = tap / g.S - g.pad;
+    b_s[p] = tap % g.S - g.pad;
+    b_cls[p] = shift_class(ci, g.fold);
+    b_off[p] = ((b_r[p] * g.W + b_s[p]) * g.Cin + ci) * 4 + b_cls[p] * frame_bytes;
+  }
+
+  const int kt_begin = split * kt_per_split;
+  const int nkt_all = (g.M + BK - 1) / BK;
+  const int kt_end = min(kt_begin + kt_per_split, nkt_all);
+
+  // INCR: the B rows of a thread advance by BK = 32 output pixels per K step, so the input position (hi, wi), the
+  // frame-in-clip index and the byte offset of the pixel are carried from step to step with two conditional wraps
+  // and additions only -- no division, modulo or integer multiply in the loop (the loader used to cost 325 VALU
+  // instructions per K step against 145 in fprop, and VALU issue is what holds the MFMA pipe of these kernels
+  // below 70 %).  The host selects INCR when a step spans less than one frame and at most Ho - 1 whole rows.
+  const int st = g.stride;
+  const int d_ho = BK / g.Wo, d_wo = BK - d_ho * g.Wo;
+  const int wrap_w = g.Wo * st, wrap_h = g.Ho * st;
+  const int px = g.Cin * 4;                                   // bytes per input pixel
+  const int inc0 = (d_ho * st * g.W + d_wo * st) * px;        // plain advance
+  const int inc1 = (st * g.W - wrap_w) * px;                  // extra when wo wraps into the next output row
+  const int inc2 = (g.H * g.W - wrap_h * g.W) * px;           // extra when ho wraps into the next frame
+  int s_hi[BP], s_wi[BP], s_t[BP], s_off[BP];
+  if (INCR) {
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+      const int m = split * kt_per_split * BK + b_krow[p];
+      const int n = m / HoWo;
+      const int rem = m - n * HoWo;
+      const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+      s_hi[p] = ho * st;
+      s_wi[p] = wo * st;
+      s_t[p] = n % g.T;
+      s_off[p] = ((n * g.H + s_hi[p]) * g.W + s_wi[p]) * px + b_off[p];
+    }
+  }
+
+  float4 ra[AP], rb[BP];
+  auto load = [&](int kt) {
+    const int m0 = kt * BK;
+#pragma unroll
+    for (int p = 0; p < AP; ++p)  // rows past M lie past num_records (the range check covers the vector offset): zeros
+      ra[p] = buf_load16(yr, a_off[p] + m0 * g.Cout * 4, 0);
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+      const int m = m0 + b_krow[p];
+      const bool mok = m < g.M;
+      int hi, wi, t, off;
+      if (INCR) {
+        hi = s_hi[p];
+        wi = s_wi[p];
+        t = s_t[p];
+        off = s_off[p];
+        const int w2 = wi + d_wo * st;
+        const bool c1 = w2 >= wrap_w;
+        s_wi[p] = c1 ? w2 - wrap_w : w2;
+        const int h2 = hi + d_ho * st + (c1 ? st : 0);
+        const bool c2 = h2 >= wrap_h;
+        s_hi[p] = c2 ? h2 - wrap_h : h2;
+        const int t2 = t + (c2 ? 1 : 0);
+        s_t[p] = t2 == g.T ? 0 : t2;
+        s_off[p] = off + inc0 + (c1 ? inc1 : 0) + (c2 ? inc2 : 0);
+      } else {  // exact integer divisions (tiny feature maps)
+        const int mm = mok ? m : 0;
+        const int n = mm / HoWo;
+        const int rem = mm - n * HoWo;
+        const int ho = rem / g.Wo;
+        hi = ho * st;
+        wi = (rem - ho * g.Wo) * st;
+        t = n % g.T;
+        off = ((n * g.H + hi) * g.W + wi) * px + b_off[p];
+      }
+      const bool v = mok && b_cok[p] && (unsigned)(hi + b_r[p]) < (unsigned)g.H && (unsigned)(wi + b_s[p]) < (unsigned)g.W &&
+                     (unsigned)(t + b_cls[p]) < (unsigned)g.T;
+      rb[p] = buf_load16(xr, off | (v ? 0 : kOOB), 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+
+  if (kt_begin < kt_end) {
+    load(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      __syncthreads();
+      store_split3_kmajor<BM, AP>(As, ra, tid);
+      store_split3_kmajor<BN, BP>(Bs, rb, tid);
+      __syncthreads();
+      if (kt + 1 < kt_end) load(kt + 1);
+      mma_stage_x3_kmajor<TM, TN, 32 * WM, 32 * WN, BM, BN>(As, Bs, acc, wm0, wn0, lane);
+    }
+  }
+
+  float* out = slab + (size_t)split * g.Cout * g.Ktot;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int col;
+    bool cok = true;
+    if (C4) {
+      col = nt * BN + wn0 + 32 * WN * j + (lane & 31);
+      cok = col < g.Ktot;
+    } else {
+      const int per_tap = g.Cin / BN;
+      const int tap = nt / per_tap;
+      col = tap * g.Cin + (nt - tap * per_tap) * BN + wn0 + 32 * WN * j + (lane & 31);
+    }
+    if (!cok) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = mt * BM + wm0 + 32 * WM * i + acc_row(e, lane);
+        out[(size_t)row * g.Ktot + col] = acc[i][j][e];
+      }
+  }
+}
+
 // dw = beta*dw + sum over splits (fixed order).  64 float4 elements x 4 split-lanes per block.
 __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ slab, float* __restrict__ dw, float beta, int splits,
                                                    int64_t numel4, int block) {
@@ -1776,7 +2022,7 @@ namespace {
 
 // main kernel of a weight gradient: split-K partial products into `slab` (plan_wgrad(gg).splits slices of dw's size)
 int wgrad_partial(const char* who, const float* dy, const float* x, const bdv_conv_geom* gg, void* workspace, size_t workspace_bytes,
-                  hipStream_t s, int* splits_out) {
+                  hipStream_t s, int* splits_out, bool x3 = false) {
   const WgradPlan p = plan_wgrad(gg);
   const size_t need = (size_t)p.splits * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(float);
   if (workspace_bytes < need) {
@@ -1801,7 +2047,14 @@ int wgrad_partial(const char* who, const float* dy, const float* x, const bdv_co
       hipLaunchKernelGGL((conv_wgrad_kernel<BMN, BMN, 2, 2, C4F, false>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,  \
                          p.kt_per_split);                                                                                      \
   } while (0)
-  if (!p.small) {
+  if (!p.small && x3) {  // experimental bf16-piece K loop (128x128 tiles only)
+    if (incr)
+      hipLaunchKernelGGL((conv_wgrad_x3_kernel<128, 128, 2, 2, false, true>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,
+                         p.kt_per_split);
+    else
+      hipLaunchKernelGGL((conv_wgrad_x3_kernel<128, 128, 2, 2, false, false>), grid, dim3(256), 0, s, dy, x, slab, g, p.MTw, p.NTw,
+                         p.kt_per_split);
+  } else if (!p.small) {
     BDV_WGRAD(128, false);
   } else if (p.c4) {
     BDV_WGRAD(64, true);
@@ -1844,6 +2097,15 @@ extern "C" int bdv_conv_wgrad_partial(const float* dy, const float* x, const bdv
   BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(slab), "bdv_conv_wgrad_partial: pointers must be 16-byte aligned");
   int splits = 0;
   return wgrad_partial("bdv_conv_wgrad_partial", dy, x, gg, slab, slab_bytes, (hipStream_t)stream, &splits);
+}
+
+extern "C" int bdv_conv_wgrad_partial_x3(const float* dy, const float* x, const bdv_conv_geom* gg, void* slab, size_t slab_bytes,
+                                         void* stream) {
+  if (int e = check_geom(gg, "bdv_conv_wgrad_partial_x3")) return e;
+  BDV_REQUIRE(dy && x && slab, "bdv_conv_wgrad_partial_x3: null pointer");
+  BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(slab), "bdv_conv_wgrad_partial_x3: pointers must be 16-byte aligned");
+  int splits = 0;
+  return wgrad_partial("bdv_conv_wgrad_partial_x3", dy, x, gg, slab, slab_bytes, (hipStream_t)stream, &splits, true);
 }
 
 extern "C" int bdv_wgrad_reduce_batched(const float* const* slabs, float* const* dws, const int* splits, const int64_t* numels,

@@ -423,7 +423,10 @@ def crop_normalize_u8(frames, crops, crop_h, crop_w, mean, std, want_nhwc4=True,
     return o4, oc
 
 
-def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom):
+WGRAD_X3 = _os.environ.get('BDVCIL_WGRAD_X3', '0') != '0'     # EXPERIMENTAL, like FPROP_X3
+
+
+def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, x3: Optional[bool] = None):
     """Split-K partial products of a weight gradient -> (slab (splits, Cout, R, S, Cin), empty dw); reduce them later with
     ``wgrad_reduce_batched`` (the slab must stay alive until then)."""
     _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
@@ -432,7 +435,8 @@ def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom):
     if splits <= 0:
         check(-1, 'bdv_conv_wgrad_splits')
     slab = torch.empty((splits, g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
-    check(lib().bdv_conv_wgrad_partial(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, _stream()), 'bdv_conv_wgrad_partial')
+    fn = lib().bdv_conv_wgrad_partial_x3 if (WGRAD_X3 if x3 is None else x3) else lib().bdv_conv_wgrad_partial
+    check(fn(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, _stream()), 'bdv_conv_wgrad_partial')
     dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
     return slab, dw
 

@@ -122,6 +122,10 @@ int bdv_conv_wgrad_partial(const float* dy, const float* x, const bdv_conv_geom*
                            void* stream);
 int bdv_wgrad_reduce_batched(const float* const* slabs, float* const* dws, const int* splits, const int64_t* numels, int n,
                              float beta, void* stream);
+/* EXPERIMENTAL counterpart of bdv_conv_fprop_x3 for the weight gradient's main kernel (128x128 tiles, i.e. Cout and Cin
+ * multiples of 128; other shapes run the fp32-MFMA kernels).  Same slab layout and split count as bdv_conv_wgrad_partial. */
+int bdv_conv_wgrad_partial_x3(const float* dy, const float* x, const bdv_conv_geom* g, void* slab, size_t slab_bytes,
+                              void* stream);
 
 /* ---- BatchNorm2d (train + eval), fused with ReLU / residual add --------------------------
  * Replaces UPSTREAM ConvModule.bn (+ .activate, + block `out + identity`) and their autograd.

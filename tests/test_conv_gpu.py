@@ -161,6 +161,30 @@ def test_dgrad_from_bf16_pieces(case, with_add, dev):
     assert torch.equal(K.conv_dgrad(dyd, wd, g, add_src=add.to(dev) if with_add else None, x3=True), d3)
 
 
+@pytest.mark.parametrize('case', [c for c in CASES if c[3] % 128 == 0 and c[4] % 128 == 0])
+def test_wgrad_from_bf16_pieces(case, dev):
+    """bdv_conv_wgrad_partial_x3 (experimental) + the batched reduction against the CPU reference and the fp32-MFMA kernel."""
+    from bdvcil_amd import kernels as K
+    N, H, W, Cin, Cout, R, st, pad, T, fold = case
+    x, w = _mk(case, 2)
+    w.requires_grad_(True)
+    y = _ref(x, w, st, pad, T, fold)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(9))
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1)
+    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    slab, dw3 = K.conv_wgrad_partial(dyd, xd, g, x3=True)
+    K.wgrad_reduce_batched([(slab, dw3)])
+    dw1 = K.conv_wgrad(dyd, xd, g)
+    _close(dw3.cpu(), ref)
+    _close(dw3.cpu(), dw1.cpu(), tol=4e-6)
+    slab2, dw3b = K.conv_wgrad_partial(dyd, xd, g, x3=True)
+    K.wgrad_reduce_batched([(slab2, dw3b)])
+    assert torch.equal(dw3, dw3b)
+
+
 def test_wgrad_partial_and_batched_reduce(dev):
     """Weight gradients left as split-K partial products and reduced together in one launch (what a stage's backward does)
     equal the one-call form bit for bit, for a batch of layers of very different sizes."""

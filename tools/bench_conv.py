@@ -38,7 +38,13 @@ for (Cin, Cout, k, st, H, cnt, sh) in SHAPES:
     flops = 2.0 * N * g.Ho * g.Wo * Cout * k * k * (3 if Cin == 4 else Cin)
     tf = timeit(lambda: K.conv_fprop(x, w, g))
     td = timeit(lambda: K.conv_dgrad(dy, w, g)) if Cin % 64 == 0 else 0.0
-    tw = timeit(lambda: K.conv_wgrad(dy, x, g))
+    if K.WGRAD_X3:   # the experimental main kernel + its reduction, as a stage's backward issues them
+        def _w():
+            slab, dw = K.conv_wgrad_partial(dy, x, g)
+            K.wgrad_reduce_batched([(slab, dw)])
+        tw = timeit(_w)
+    else:
+        tw = timeit(lambda: K.conv_wgrad(dy, x, g))
     print(f'{str((Cin, Cout, k, st, H)):28s} x{cnt:<3d} {flops/1e9:7.1f} | {tf:8.3f} {flops/tf/1e9:6.1f} | {td:8.3f} {(flops/td/1e9 if td else 0):6.1f} | {tw:8.3f} {flops/tw/1e9:6.1f}')
     tot['fprop'] += tf * cnt; tot['dgrad'] += td * cnt; tot['wgrad'] += tw * cnt
     totf += flops * cnt
