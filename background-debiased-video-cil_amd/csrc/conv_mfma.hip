@@ -791,42 +791,39 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_x3_kernel(const float* __re
 }
 
 // wgrad variant of the bf16-piece loop: both operands arrive contiguous along channels, not along the contraction (pixels).
-// The three planes are stored k-major, [plane][32 k rows][COLS + 8] bf16 (8-byte stores, like the fp32 image), and a lane
-// gathers its 8 consecutive k values of one channel with 16-bit LDS reads (32 lanes read 64 contiguous bytes of a row:
-// conflict-free).  Eight times the LDS read instructions of the row-major image, still cheaper than fp32 MFMAs.
-template <int COLS>
-struct X3KMajor {
-  static constexpr int LDW = COLS + 8;         // bf16 per k row
-  static constexpr int PLANE = BK * LDW;       // bf16 per plane
-};
+// A thread loads rows k and k + 1 of its 4 channels, and the LDS image of a plane is [16 k-pairs][COLS] 32-bit words, a word
+// holding the bf16 pieces of (k, k + 1) of one channel: written with 16-byte stores, and a lane collects its 8 consecutive k
+// of one channel with four ds_read_b32 whose words already have the element order of the MFMA operand (32 lanes read 128
+// contiguous bytes: conflict-free).  Four times the LDS read instructions of the row-major image of fprop / dgrad.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int X3_PAIR_ROWS = BK / 2;
 
+// v[2q], v[2q+1] = rows (k, k+1) of k-pair  kp = tid / V + 8 q, channels 4 (tid % V) .. + 3
 template <int COLS, int PASSES>
-__device__ __forceinline__ void store_split3_kmajor(unsigned short* __restrict__ dst, const float4 (&v)[PASSES], int tid) {
-  constexpr int V = COLS / 4;
-  constexpr int LDW = X3KMajor<COLS>::LDW, PLANE = X3KMajor<COLS>::PLANE;
+__device__ __forceinline__ void store_split3_pairs(unsigned* __restrict__ dst, const float4 (&v)[PASSES], int tid) {
+  constexpr int V = COLS / 4, PLANE = X3_PAIR_ROWS * COLS;
+  static_assert(PASSES == 4 && 256 / V == 8, "row assignment below: 8 row groups x 2 rows x 2 halves");
+  const int c4 = tid % V, rg = tid / V;
 #pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
-    const int idx = tid + 256 * p;
-    const int krow = idx / V, c4 = idx - krow * V;
-    const f32x4_t a = {v[p].x, v[p].y, v[p].z, v[p].w};
-    const bf16x4_t hi = __builtin_convertvector(a, bf16x4_t);
-    const f32x4_t r1 = a - __builtin_convertvector(hi, f32x4_t);
-    const bf16x4_t mid = __builtin_convertvector(r1, bf16x4_t);
-    const f32x4_t r2 = r1 - __builtin_convertvector(mid, f32x4_t);
-    const bf16x4_t lo = __builtin_convertvector(r2, bf16x4_t);
-    unsigned short* q = dst + krow * LDW + 4 * c4;
-    *reinterpret_cast<bf16x4_t*>(q) = hi;
-    *reinterpret_cast<bf16x4_t*>(q + PLANE) = mid;
-    *reinterpret_cast<bf16x4_t*>(q + 2 * PLANE) = lo;
+  for (int q = 0; q < 2; ++q) {
+    const f32x4_t e = {v[2 * q].x, v[2 * q].y, v[2 * q].z, v[2 * q].w};
+    const f32x4_t o = {v[2 * q + 1].x, v[2 * q + 1].y, v[2 * q + 1].z, v[2 * q + 1].w};
+    const bf16x4_t eh = __builtin_convertvector(e, bf16x4_t), oh = __builtin_convertvector(o, bf16x4_t);
+    const f32x4_t e1 = e - __builtin_convertvector(eh, f32x4_t), o1 = o - __builtin_convertvector(oh, f32x4_t);
+    const bf16x4_t em = __builtin_convertvector(e1, bf16x4_t), om = __builtin_convertvector(o1, bf16x4_t);
+    const f32x4_t e2 = e1 - __builtin_convertvector(em, f32x4_t), o2 = o1 - __builtin_convertvector(om, f32x4_t);
+    const bf16x4_t el = __builtin_convertvector(e2, bf16x4_t), ol = __builtin_convertvector(o2, bf16x4_t);
+    unsigned* w = dst + (rg + 8 * q) * COLS + 4 * c4;
+    *reinterpret_cast<bf16x8_t*>(w) = __builtin_shufflevector(eh, oh, 0, 4, 1, 5, 2, 6, 3, 7);
+    *reinterpret_cast<bf16x8_t*>(w + PLANE) = __builtin_shufflevector(em, om, 0, 4, 1, 5, 2, 6, 3, 7);
+    *reinterpret_cast<bf16x8_t*>(w + 2 * PLANE) = __builtin_shufflevector(el, ol, 0, 4, 1, 5, 2, 6, 3, 7);
   }
 }
 
 template <int TM, int TN, int MS, int NS, int COLS_A, int COLS_B>
-__device__ __forceinline__ void mma_stage_x3_kmajor(const unsigned short* __restrict__ As, const unsigned short* __restrict__ Bs,
-                                                    f32x16 (&acc)[TM][TN], int wm0, int wn0, int lane) {
-  constexpr int LDA = X3KMajor<COLS_A>::LDW, PA = X3KMajor<COLS_A>::PLANE;
-  constexpr int LDB = X3KMajor<COLS_B>::LDW, PB = X3KMajor<COLS_B>::PLANE;
-  typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mma_stage_x3_pairs(const unsigned* __restrict__ As, const unsigned* __restrict__ Bs,
+                                                   f32x16 (&acc)[TM][TN], int wm0, int wn0, int lane) {
+  constexpr int PA = X3_PAIR_ROWS * COLS_A, PB = X3_PAIR_ROWS * COLS_B;
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int s = 0; s < BK / 16; ++s) {
@@ -835,16 +832,16 @@ __device__ __forceinline__ void mma_stage_x3_kmajor(const unsigned short* __rest
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        u16x8_t f;
+        u32x4_t f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = As[p * PA + (16 * s + 8 * h + e) * LDA + wm0 + MS * i + r];
+        for (int e = 0; e < 4; ++e) f[e] = As[p * PA + (8 * s + 4 * h + e) * COLS_A + wm0 + MS * i + r];
         a[p][i] = __builtin_bit_cast(bf16x8_t, f);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        u16x8_t f;
+        u32x4_t f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = Bs[p * PB + (16 * s + 8 * h + e) * LDB + wn0 + NS * j + r];
+        for (int e = 0; e < 4; ++e) f[e] = Bs[p * PB + (8 * s + 4 * h + e) * COLS_B + wn0 + NS * j + r];
         b[p][j] = __builtin_bit_cast(bf16x8_t, f);
       }
     }
@@ -1437,13 +1434,14 @@ template <int BM, int BN, int WM, int WN, bool C4, bool INCR>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           float* __restrict__ slab, Geom g, int MTw, int NTw,
                                                           int kt_per_split) {
-  // bf16-piece variant of conv_wgrad_kernel (see conv_fprop_x3_kernel / mma_stage_x3_kmajor)
+  // bf16-piece variant of conv_wgrad_kernel (see conv_fprop_x3_kernel / mma_stage_x3_pairs)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
   constexpr int AV = BM / 4, BV = BN / 4;
-  __shared__ __attribute__((aligned(16))) unsigned short smem16[3 * (X3KMajor<BM>::PLANE + X3KMajor<BN>::PLANE)];
-  unsigned short* const As = smem16;
-  unsigned short* const Bs = smem16 + 3 * X3KMajor<BM>::PLANE;
+  static_assert(BM == 128 && BN == 128, "row-pair assignment of the loader");
+  __shared__ __attribute__((aligned(16))) unsigned smem32[3 * X3_PAIR_ROWS * (BM + BN)];
+  unsigned* const As = smem32;
+  unsigned* const Bs = smem32 + 3 * X3_PAIR_ROWS * BM;
 
   // All tiles of one K slice read the same rows of dy and (up to the filter halo) of x.  Work index w = slice * tiles + tile,
   // handed out so that one XCD gets a contiguous range of w: the tiles of a slice then run at the same time behind the
@@ -1466,8 +1464,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
   int a_off[AP];
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
-    const int idx = tid + 256 * p;
-    const int krow = idx / AV, c4 = idx - krow * AV;
+    const int c4 = tid % AV;
+    const int krow = 2 * (tid / AV) + (p & 1) + 16 * (p >> 1);  // rows (k, k+1) of a k-pair sit in one thread
     a_off[p] = (krow * g.Cout + mt * BM + 4 * c4) * 4;
   }
   // B: column -> (tap, ci) for this thread's loads (fixed over the K loop)
@@ -1475,8 +1473,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
   bool b_cok[BP];
 #pragma unroll
   for (int p = 0; p < BP; ++p) {
-    const int idx = tid + 256 * p;
-    const int krow = idx / BV, c4 = idx - krow * BV;
+    const int c4 = tid % BV;
+    const int krow = 2 * (tid / BV) + (p & 1) + 16 * (p >> 1);
     b_krow[p] = krow;
     int tap, ci;
     if (C4) {
@@ -1575,11 +1573,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
     load(kt_begin);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       __syncthreads();
-      store_split3_kmajor<BM, AP>(As, ra, tid);
-      store_split3_kmajor<BN, BP>(Bs, rb, tid);
+      store_split3_pairs<BM, AP>(As, ra, tid);
+      store_split3_pairs<BN, BP>(Bs, rb, tid);
       __syncthreads();
       if (kt + 1 < kt_end) load(kt + 1);
-      mma_stage_x3_kmajor<TM, TN, 32 * WM, 32 * WN, BM, BN>(As, Bs, acc, wm0, wn0, lane);
+      mma_stage_x3_pairs<TM, TN, 32 * WM, 32 * WN, BM, BN>(As, Bs, acc, wm0, wn0, lane);
     }
   }
 
