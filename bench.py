@@ -158,6 +158,8 @@ def main():
                          "+ representations of BaseCIL.predict_step (SURVEY section 8(f) rank 1), no backward")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-experimental', action='store_true',
+                    help='skip the extra, separately reported run with the bf16-piece K loops switched on (DESIGN.md section 8)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -258,6 +260,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # Reported beside the metric, never as it: the same K steps with the experimental conv K loops that form every fp32
+    # product from three bf16 pieces per operand (bdv_conv_*_x3).  `value` above is the fp32-MFMA path.
+    dtx = None
+    if not args.no_experimental and not (K.FPROP_X3 or K.DGRAD_X3 or K.WGRAD_X3):
+        K.FPROP_X3 = K.DGRAD_X3 = K.WGRAD_X3 = True
+        try:
+            timer.enabled = False
+            for _ in range(min(args.warmup, 3)):
+                engine.step(batch, loss_fn)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                engine.step(batch, loss_fn)
+            sync()
+            dtx = time.perf_counter() - t0
+            if use_dist:
+                t = torch.tensor([dtx], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dtx = float(t.item())
+        finally:
+            K.FPROP_X3 = K.DGRAD_X3 = K.WGRAD_X3 = False
+
     if rank == 0:
         clips = args.batch * world * args.steps
         value = clips / dt
@@ -300,6 +324,12 @@ def main():
                 'conv_ms_per_step': round(tot_ms / timed_steps, 3), 'conv_tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                 'kernel_timed_steps': timed_steps,
             }
+        if dtx is not None:
+            res['experimental_bf16_pieces'] = {
+                'value': round(clips / dtx, 2), 'unit': 'clips/s', 'ms_per_step': round(1000.0 * dtx / args.steps, 3),
+                'note': 'NOT the metric: same steps with BDVCIL_FPROP_X3 / DGRAD_X3 / WGRAD_X3 (fp32 products from three bf16 '
+                        'pieces per operand, six bf16 MFMAs per K-step, fp32 accumulate; error at the level of an fp32 FMA chain, '
+                        'DESIGN.md section 8); off by default'}
         if world == 1 and not args.no_cpu_baseline and not cil and not predict:
             res['cpu_baseline'] = cpu_baseline(args.depth, args.classes, args.head, args.loss)
         print(json.dumps(res), flush=True)
