@@ -279,6 +279,9 @@ def main():
                 t = torch.tensor([dtx], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dtx = float(t.item())
+        except Exception as e:      # the metric above must be reported whatever happens in the side measurement
+            print(f'[bench] experimental run failed: {e!r}', file=sys.stderr, flush=True)
+            dtx = None
         finally:
             K.FPROP_X3 = K.DGRAD_X3 = K.WGRAD_X3 = False
 
