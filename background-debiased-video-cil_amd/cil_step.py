@@ -65,9 +65,14 @@ def icarl_training_step(current_model: nn.Module, batch_data: Dict[str, torch.Te
                         current_task: int = 0, prev_model: Optional[nn.Module] = None,
                         previous_task_num_classes: int = 0) -> torch.Tensor:
     """libs/cil/icarl.py:97-125, including the soft labels of the ``foreground_ratio`` branch (:103-111; like the
-    reference it rewrites ``batch_data['background_label']`` -1 -> 0 in place).  The prev model is evaluated on the whole
-    batch and only old-class rows are used (same values as the reference's ``imgs[indices]`` gather: eval-mode BN makes
-    rows independent)."""
+    reference it rewrites ``batch_data['background_label']`` -1 -> 0 in place).
+
+    Deliberate deviation (parity unpinned, no fixture covers it): the teacher runs in EVAL mode (running BatchNorm
+    statistics, no dropout) on the whole batch and only its old-class rows are used.  ``ICARLModel.training_step`` never
+    calls ``prev_model.eval()`` (unlike ``BaseCIL`` at cil.py:520), so under Lightning's ``fit`` the reference's teacher
+    runs in train mode on ``imgs[indices]`` alone: batch-statistics BatchNorm over the old-class clips of the batch,
+    dropout 0.5 on its features, and running statistics that drift with every step.  A frozen teacher is what the
+    method describes; with eval-mode BatchNorm the rows are independent, so evaluating the whole batch equals the gather."""
     imgs, targets = batch_data['imgs'], batch_data['label']
     cls_score = current_model(imgs, return_loss=False)
     base = None

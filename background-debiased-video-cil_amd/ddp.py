@@ -130,6 +130,9 @@ class GradAllReducer:
             import contextlib
             ctx = contextlib.nullcontext()
         with ctx, torch.no_grad():
+            # a parameter without a gradient this step contributes zeros to the sum; it is remembered so that finish()
+            # leaves its .grad at None (no rank used it: the optimizer must skip it, as torch's DDP + SGD do)
+            b.no_grad = [p.grad is None for p in b.params]
             grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
             torch._foreach_copy_(b.views, grads)                      # pack (copy plumbing, no arithmetic)
             if on_gpu:
@@ -151,6 +154,6 @@ class GradAllReducer:
                 b.work.wait()
             if b.event is not None:
                 torch.cuda.current_stream().wait_event(b.event)
-            for p, v in zip(b.params, b.views):
-                p.grad = v
+            for p, v, skipped in zip(b.params, b.views, getattr(b, 'no_grad', None) or [False] * len(b.params)):
+                p.grad = None if skipped else v
         self.reset()

@@ -44,6 +44,11 @@ FUSE_STAGE = _os.environ.get('BDVCIL_FUSE_STAGE', '1') != '0'
 BATCH_WGRAD_REDUCE = _os.environ.get('BDVCIL_BATCH_WGRAD_REDUCE', '1') != '0'
 
 
+# Test hook: when set to a list, every training-mode forward appends the 1-bit ReLU masks it writes, in execution order
+# (stem, then per block: unit 0, unit 1, ..., block output); the parity tests compare them with the CPU reference's signs.
+RELU_MASK_TAP = None
+
+
 def set_side_stream_enabled(flag: bool):
     _SIDE['enabled'] = bool(flag)
 
@@ -178,6 +183,8 @@ class StemFn(torch.autograd.Function):
             y, mean, invstd, scale, shift = _conv_bn_forward(x4, w4, g, bn, gamma, beta, training)
             # BN apply + ReLU + max-pool + ReLU sign mask in one pass; the activation itself is never materialised
             p, idx, mask = K.bn_relu_maxpool_fwd(y, scale, shift)
+            if RELU_MASK_TAP is not None:
+                RELU_MASK_TAP.append((tuple(y.shape), mask))
             a_shape = tuple(y.shape)
         else:
             a = _conv_bn_eval(x4, w4, g, bn, gamma, beta, None, True)
@@ -247,6 +254,8 @@ def _block_forward(x, blk, training, params, save):
             a, mask = K.bn_apply(y, sc, sh, identity if last else None, True, want_mask=True,
                                  res_affine=id_affine if last else None)
             saved += [y, a, mean, invstd, mask]
+            if RELU_MASK_TAP is not None:
+                RELU_MASK_TAP.append((tuple(y.shape), mask))
         else:
             a = K.bn_apply(y, sc, sh, identity if last else None, True, res_affine=id_affine if last else None)
         cur = a

@@ -12,13 +12,29 @@ from . import kernels as K
 from .registry import HEADS, build_loss
 
 
+def _grown(old: torch.Tensor, rows: int) -> torch.Tensor:
+    """A (rows, ...) tensor like ``old`` whose first ``len(old)`` rows are ``old`` and whose other rows are freshly drawn
+    kaiming-normal values (the whole tensor is drawn first, as the reference does, so the random stream is consumed
+    identically: cosine_linear.py:45-50, inc_net.py:23-34)."""
+    out = old.new_empty((rows,) + tuple(old.shape[1:]))
+    if out.dim() > 1:
+        nn.init.kaiming_normal_(out, nonlinearity='linear')
+    else:
+        out.zero_()
+    out[:old.shape[0]].copy_(old)
+    return out
+
+
 class LSC(nn.Module):
-    """Local Similarity Classifier, libs/models/cil_heads/cosine_linear.py:6-55."""
+    """Local Similarity Classifier (plugin surface of libs/models/cil_heads/cosine_linear.py:6-55): ``weights`` is
+    (out_features, nb_proxies * in_features); the forward is the fused HIP kernel."""
 
     def __init__(self, in_features: int, out_features: int, nb_proxies: int = 3):
         super().__init__()
-        self.in_features, self.out_features, self.nb_proxies = in_features, out_features, nb_proxies
-        self.weights = nn.Parameter(torch.empty(out_features, self.nb_proxies * in_features), requires_grad=True)
+        self.in_features = in_features
+        self.out_features = out_features
+        self.nb_proxies = nb_proxies
+        self.weights = nn.Parameter(torch.empty(out_features, nb_proxies * in_features))
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -28,43 +44,37 @@ class LSC(nn.Module):
         return Fn.LSCFn.apply(x, self.weights, self.out_features, self.nb_proxies)
 
     def update_fc(self, nb_classes):
-        new_weight = torch.empty(nb_classes, self.nb_proxies * self.in_features).type_as(self.weights.data)
-        nn.init.kaiming_normal_(new_weight, nonlinearity='linear')
-        new_weight[:self.out_features] = self.weights.data
-        self.weights = nn.Parameter(new_weight, requires_grad=True)
+        """Grow to ``nb_classes`` rows keeping the old ones; ``weights`` becomes a NEW Parameter object (the optimizer is
+        rebuilt per task)."""
+        self.weights = nn.Parameter(_grown(self.weights.data, nb_classes), requires_grad=True)
         self.out_features = nb_classes
 
     def __repr__(self):
-        return 'LocalSimilarityClassifier(in_features: {}, out_features: {}, nb_proxies: {})'.format(
-            self.in_features, self.out_features, self.nb_proxies)
+        return (f'LocalSimilarityClassifier(in_features: {self.in_features}, out_features: {self.out_features}, '
+                f'nb_proxies: {self.nb_proxies})')
 
 
 class IncrementalNet(nn.Module):
-    """Growable linear layer, libs/models/cil_heads/inc_net.py:6-37."""
+    """Growable linear layer (plugin surface of libs/models/cil_heads/inc_net.py:6-37)."""
 
     def __init__(self, in_features: int, out_features: int, bias=True):
         super().__init__()
-        self.in_features, self.out_features = in_features, out_features
-        self.weight = nn.Parameter(torch.Tensor(out_features, in_features))
+        self.in_features = in_features
+        self.out_features = out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
         if bias:
-            self.bias = nn.Parameter(torch.Tensor(out_features))
+            self.bias = nn.Parameter(torch.empty(out_features))
         else:
             self.register_parameter('bias', None)
         self.reset_parameters()
 
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight, nonlinearity='linear')
-        nn.init.constant_(self.bias, 0)
+        nn.init.constant_(self.bias, 0)             # like the reference, bias=False fails here
 
     def update_fc(self, nb_classes):
-        new_weight = torch.empty(nb_classes, self.in_features).type_as(self.weight.data)
-        nn.init.kaiming_normal_(new_weight, nonlinearity='linear')
-        new_weight[:self.out_features] = self.weight.data
-        self.weight = nn.Parameter(new_weight, requires_grad=True)
-        new_bias = torch.empty(nb_classes).type_as(self.bias.data)
-        nn.init.constant_(new_bias, 0)
-        new_bias[:self.out_features] = self.bias.data
-        self.bias = nn.Parameter(new_bias, requires_grad=True)
+        self.weight = nn.Parameter(_grown(self.weight.data, nb_classes), requires_grad=True)
+        self.bias = nn.Parameter(_grown(self.bias.data, nb_classes), requires_grad=True)     # new entries zero
         self.out_features = nb_classes
 
     def forward(self, x):
@@ -94,17 +104,23 @@ class AvgPool2dTo1(nn.Module):
         return Fn.AvgPoolFn.apply(x)
 
 
+_DROPOUT_DRAWS = [0]      # per process, shared by all HipDropout instances: rebuilding a model does not replay the masks
+
+
 class HipDropout(nn.Module):
+    """nn.Dropout with a counter-based generator in the kernel.  The 64-bit seed of a call mixes torch's initial seed, the
+    rank of the process (ranks seeded alike still draw different masks) and the number of draws made so far."""
+
     def __init__(self, p):
         super().__init__()
         self.p = p
-        self._calls = 0
 
     def forward(self, x):
         if not self.training or self.p == 0:
             return x
-        self._calls += 1
-        seed = (torch.initial_seed() * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
+        _DROPOUT_DRAWS[0] += 1
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        seed = ((torch.initial_seed() * 1000003 + rank) * 1000003 + _DROPOUT_DRAWS[0]) & 0x7FFFFFFFFFFFFFFF
         return Fn.DropoutFn.apply(x, float(self.p), seed)
 
 

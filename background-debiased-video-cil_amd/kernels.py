@@ -66,8 +66,29 @@ def _conv_ws(g: ConvGeom, kind: int, device, tag: str) -> torch.Tensor:
 
 import os as _os
 
-# EXPERIMENTAL: forward convolutions with fp32 products formed from bf16 pieces (bdv_conv_fprop_x3)
-FPROP_X3 = _os.environ.get('BDVCIL_FPROP_X3', '0') != '0'
+# Arithmetic of the 128-wide convolution tiles.  Default: every fp32 product is formed from three
+# bf16 pieces per operand (six v_mfma_f32_32x32x16_bf16 products of relative weight >= 2^-16, fp32 accumulate; the dropped
+# terms are below 2^-24 relative, the level of fp32 rounding).  BDVCIL_CONV_F32MFMA=1 selects the v_mfma_f32_32x32x2_f32
+# kernels (an exact fp32 FMA chain) for all three directions; the per-direction switches override it.
+_F32MFMA = _os.environ.get('BDVCIL_CONV_F32MFMA', '0') != '0'
+
+
+def _x3_default(name):
+    v = _os.environ.get(name)
+    return (not _F32MFMA) if v is None else v != '0'
+
+
+FPROP_X3 = _x3_default('BDVCIL_FPROP_X3')
+
+
+def set_conv_arith(mode: str):
+    """'bf16x3' (default) or 'f32mfma' for fprop, dgrad and wgrad at once; returns the previous (fprop, dgrad, wgrad) flags."""
+    global FPROP_X3, DGRAD_X3, WGRAD_X3
+    if mode not in ('bf16x3', 'f32mfma'):
+        raise ValueError(f"set_conv_arith: unknown mode {mode!r} ('bf16x3' | 'f32mfma')")
+    prev = (FPROP_X3, DGRAD_X3, WGRAD_X3)
+    FPROP_X3 = DGRAD_X3 = WGRAD_X3 = (mode == 'bf16x3')
+    return prev
 
 
 def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torch.Tensor] = None,
@@ -102,7 +123,7 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
     return (y, part) if bn_stats else y
 
 
-DGRAD_X3 = _os.environ.get('BDVCIL_DGRAD_X3', '0') != '0'     # EXPERIMENTAL, like FPROP_X3
+DGRAD_X3 = _x3_default('BDVCIL_DGRAD_X3')
 
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional[torch.Tensor] = None,
@@ -146,13 +167,18 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
 
 
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, dw: Optional[torch.Tensor] = None,
-               beta: float = 0.0, ws_tag: str = 'wgrad') -> torch.Tensor:
+               beta: float = 0.0, ws_tag: str = 'wgrad', x3: Optional[bool] = None) -> torch.Tensor:
+    """dw = beta * dw + dy^T (*) x in one call (split-K main kernel + fixed-order reduction)."""
     _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
     _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
     if dw is None:
         dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
         beta = 0.0
     _chk(dw, (g.Cout, g.R, g.S, g.Cin), name='dw')
+    if WGRAD_X3 if x3 is None else x3:      # the bf16-piece main kernel only exists in the partial + reduce form
+        slab, _ = conv_wgrad_partial(dy, x, g, x3=True, dw=dw)
+        wgrad_reduce_batched([(slab, dw)], beta=beta)
+        return dw
     ws = _conv_ws(g, 2, dy.device, ws_tag)
     check(lib().bdv_conv_wgrad(_p(dy), _p(x), _p(dw), float(beta), ctypes.byref(g), _p(ws), ws.numel(), _stream()),
           'bdv_conv_wgrad')
@@ -423,10 +449,11 @@ def crop_normalize_u8(frames, crops, crop_h, crop_w, mean, std, want_nhwc4=True,
     return o4, oc
 
 
-WGRAD_X3 = _os.environ.get('BDVCIL_WGRAD_X3', '0') != '0'     # EXPERIMENTAL, like FPROP_X3
+WGRAD_X3 = _x3_default('BDVCIL_WGRAD_X3')
 
 
-def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, x3: Optional[bool] = None):
+def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, x3: Optional[bool] = None,
+                       dw: Optional[torch.Tensor] = None):
     """Split-K partial products of a weight gradient -> (slab (splits, Cout, R, S, Cin), empty dw); reduce them later with
     ``wgrad_reduce_batched`` (the slab must stay alive until then)."""
     _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
@@ -437,7 +464,8 @@ def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, x3: Optio
     slab = torch.empty((splits, g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
     fn = lib().bdv_conv_wgrad_partial_x3 if (WGRAD_X3 if x3 is None else x3) else lib().bdv_conv_wgrad_partial
     check(fn(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, _stream()), 'bdv_conv_wgrad_partial')
-    dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
+    if dw is None:
+        dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
     return slab, dw
 
 

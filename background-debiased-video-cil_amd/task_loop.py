@@ -55,40 +55,52 @@ class AttrDict(dict):
 
 
 class AverageMeter:
-    """libs/utils.py:8-26."""
+    """Per-task accuracies of one evaluation round with their sample counts (the record ``libs/utils.py:8-26`` keeps):
+    ``values`` in the order they were added, ``avg`` their sample-weighted mean."""
 
     def __init__(self):
-        self.reset()
+        self.values: List[float] = []
+        self.sizes: List[int] = []
 
     def reset(self):
-        self.values, self.sizes = [], []
-        self.avg = 0
-        self.sum = 0
-        self.count = 0
+        del self.values[:], self.sizes[:]
 
     def update(self, val, n=1):
         self.values.append(val)
         self.sizes.append(n)
-        self.sum += val * n
-        self.count += n
-        self.avg = self.sum / self.count
+
+    @property
+    def count(self):
+        return sum(self.sizes)
+
+    @property
+    def sum(self):
+        total = 0
+        for v, n in zip(self.values, self.sizes):       # same accumulation order as a running sum
+            total += v * n
+        return total
+
+    @property
+    def avg(self):
+        return self.sum / self.count if self.sizes else 0
 
 
 def print_mean_accuracy(accuracies: List[AverageMeter], num_classes_per_task, floatfmt='.2f') -> str:
-    """The accuracy table written to ``cnn_result.txt`` / ``nme_result.txt`` (libs/utils.py:29-48)."""
+    """The accuracy table written to ``cnn_result.txt`` / ``nme_result.txt``, in the layout of libs/utils.py:29-48: one
+    column per task's class range, one row per evaluated task (blank where a task did not exist yet), the weighted
+    average last, and a final row with the mean of the averages."""
     from tabulate import tabulate
-    assert len(accuracies) == len(num_classes_per_task)
     num_tasks = len(num_classes_per_task)
-    headers, start = ['range'], 0
-    for n in num_classes_per_task:
-        headers.append('{}-{}'.format(start, start + n - 1))
-        start += n
-    headers.append('Avg')
-    table = []
-    for i in range(num_tasks):
-        table.append(['task {}'.format(i), *accuracies[i].values] + (num_tasks - i - 1) * [None] + [accuracies[i].avg])
-    table.append(['avg_acc'] + num_tasks * [None] + [np.mean([a.avg for a in accuracies])])
-    return tabulate(table, headers=headers, floatfmt=[floatfmt] * 8, missingval='')
+    if len(accuracies) != num_tasks:
+        raise AssertionError(f'{len(accuracies)} accuracy rows for {num_tasks} tasks')
+    bounds = np.concatenate([[0], np.cumsum(num_classes_per_task)])
+    headers = ['range'] + [f'{int(lo)}-{int(hi) - 1}' for lo, hi in zip(bounds[:-1], bounds[1:])] + ['Avg']
+    rows = []
+    for t, meter in enumerate(accuracies):
+        cells = list(meter.values) + [None] * (num_tasks - 1 - t)
+        rows.append([f'task {t}'] + cells + [meter.avg])
+    rows.append(['avg_acc'] + [None] * num_tasks + [np.mean([m.avg for m in accuracies])])
+    return tabulate(rows, headers=headers, floatfmt=[floatfmt] * 8, missingval='')
 
 
 # ---- task splits and the files on disk --------------------------------------------------------------------------------
@@ -354,6 +366,11 @@ class CILTaskLoop:
         for p in self.prev_model.parameters():
             p.requires_grad_(False)
         self.prev_model.eval()
+        if self.method in ('icarl', 'icarl_video_mix'):
+            # libs/cil/icarl.py:34,:39: the iCaRL step trains on raw scores and feeds the teacher's scores to a softmax of
+            # its own, whatever the config's test_cfg says (every shipped iCaRL config says 'prob')
+            self.current_model.test_cfg['average_clips'] = 'score'
+            self.prev_model.test_cfg['average_clips'] = 'score'
         broadcast_parameters(self.current_model)
         self.repr_module_name = config.get('repr_hook', 'cls_head.avg_pool')
         self.current_hooks = self.prev_hooks = None
@@ -409,7 +426,17 @@ class CILTaskLoop:
                                                       self.config.data_root, phase='train'))
 
     def _load_state(self, model, path):
+        """Every rank reads a checkpoint rank 0 wrote: wait for the writer first (a collective on the GPU stream does not
+        order host file I/O)."""
+        self._barrier()
         model.load_state_dict(torch.load(path, map_location=self.device, weights_only=True))
+
+    def _save_state(self, obj, path):
+        """Rank-0 write that other ranks can never see half-done: temporary file, then an atomic rename."""
+        if self.rank == 0:
+            tmp = f'{path}.tmp{os.getpid()}'
+            torch.save(obj, tmp)
+            os.replace(tmp, path)
 
     def _resume(self):
         """libs/cil/cil.py:659-696: rebuild exemplars (from disk, or by re-extracting them), roll back one task to
@@ -487,6 +514,19 @@ class CILTaskLoop:
         if accum > 1 and reducer is not None:
             raise NotImplementedError('accumulate_grad_batches > 1 with several ranks (the 8-GPU setting of the configs uses 1)')
         epoch_losses = []
+        try:
+            self._fit_epochs(records, max_epochs, validate, optimizer, scheduler, reducer, clip, accum, epoch_losses)
+        finally:
+            if reducer is not None:
+                reducer.remove()        # also on an exception: stale post-accumulate hooks would fire collectives in the next fit
+        if reducer is not None:
+            # DDP keeps module buffers equal to rank 0's at every forward; do it once per fit here
+            for b in self.current_model.buffers():
+                dist.broadcast(b.data, 0)
+        return epoch_losses
+
+    def _fit_epochs(self, records, max_epochs, validate, optimizer, scheduler, reducer, clip, accum, epoch_losses):
+        cfg = self.config
         for epoch in range(max_epochs):
             self.current_model.train()
             batches = epoch_batches(len(records), cfg.videos_per_gpu, True, self._shuffle_gen, self.rank, self.world)
@@ -511,12 +551,6 @@ class CILTaskLoop:
             epoch_losses.append(float(total) / max(len(batches), 1))
             if validate:
                 self._validation_epoch()
-        if reducer is not None:
-            reducer.remove()
-            # DDP keeps module buffers equal to rank 0's at every forward; do it once per fit here
-            for b in self.current_model.buffers():
-                dist.broadcast(b.data, 0)
-        return epoch_losses
 
     def _validation_epoch(self):
         """``validation_step`` / ``validation_epoch_end`` (libs/cil/cil.py:580-618): CNN accuracy over the validation
@@ -529,8 +563,7 @@ class CILTaskLoop:
         if self.current_best < acc.avg:
             self.log('Accuracy improve from {} to {}'.format(self.current_best, acc.avg))
             self.current_best = acc.avg
-            if self.rank == 0:
-                torch.save(self.current_model.state_dict(), self.files.ckpt_file(self._current_task))
+            self._save_state(self.current_model.state_dict(), self.files.ckpt_file(self._current_task))
         return acc
 
     def train_task(self) -> List[float]:
@@ -627,8 +660,7 @@ class CILTaskLoop:
         repr_ = torch.cat([b['mean_crops_repr_'] for b in pred_], dim=0)
         label = torch.cat([b['label'] for b in pred_], dim=0).squeeze(dim=1)
         class_means = class_means_from_repr(repr_, label, self.num_classes(task_idx))
-        if self.rank == 0:
-            torch.save({'class_means': class_means}, path)
+        self._save_state({'class_means': class_means}, path)
         self._barrier()
         return class_means
 
@@ -668,8 +700,7 @@ class CILTaskLoop:
             if save_best:
                 self._load_state(self.current_model, self.files.ckpt_file(t))
             else:
-                if self.rank == 0:
-                    torch.save(self.current_model.state_dict(), self.files.ckpt_file(t))
+                self._save_state(self.current_model.state_dict(), self.files.ckpt_file(t))
                 self._barrier()
             class_means = self._get_exemplar_class_means(t, override_class_mean_ckpt=True)
             record['cnn'], record['nme'] = self._testing([0, t], val_test='val', exemplar_class_means=class_means)

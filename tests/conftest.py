@@ -18,3 +18,13 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip('no GPU visible')
     return torch.device('cuda:0')
+
+
+@pytest.fixture(params=['bf16x3', 'f32mfma'])
+def conv_arith(request):
+    """Runs a test once per conv arithmetic: the default (fp32 products from three bf16 pieces per operand, six bf16 MFMA
+    products) and the v_mfma_f32_32x32x2_f32 kernels."""
+    from bdvcil_amd import kernels as K
+    prev = K.set_conv_arith(request.param)
+    yield request.param
+    K.FPROP_X3, K.DGRAD_X3, K.WGRAD_X3 = prev

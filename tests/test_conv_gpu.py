@@ -51,7 +51,7 @@ def _close(a, b, tol=2e-5):
 
 
 @pytest.mark.parametrize('case', CASES)
-def test_fprop(case, dev):
+def test_fprop(case, dev, conv_arith):
     from bdvcil_amd import kernels as K
     N, H, W, Cin, Cout, R, st, pad, T, fold = case
     x, w = _mk(case)
@@ -64,7 +64,7 @@ def test_fprop(case, dev):
 
 @pytest.mark.parametrize('case', [c for c in CASES if c[3] % 64 == 0])
 @pytest.mark.parametrize('with_add', [False, True])
-def test_dgrad(case, with_add, dev):
+def test_dgrad(case, with_add, dev, conv_arith):
     from bdvcil_amd import kernels as K
     N, H, W, Cin, Cout, R, st, pad, T, fold = case
     x, w = _mk(case, 1)
@@ -91,7 +91,7 @@ def test_dgrad(case, with_add, dev):
 
 
 @pytest.mark.parametrize('case', CASES)
-def test_wgrad(case, dev):
+def test_wgrad(case, dev, conv_arith):
     from bdvcil_amd import kernels as K
     N, H, W, Cin, Cout, R, st, pad, T, fold = case
     x, w = _mk(case, 2)
@@ -114,7 +114,7 @@ def test_wgrad(case, dev):
 
 @pytest.mark.parametrize('case', [c for c in CASES if c[4] % 128 == 0 and c[3] % 32 == 0])
 def test_fprop_from_bf16_pieces(case, dev):
-    """bdv_conv_fprop_x3 (experimental): fp32 products formed from three bf16 pieces per operand value.  Same tolerance as
+    """bdv_conv_fprop_x3 (the default arithmetic): fp32 products formed from three bf16 pieces per operand value.  Same tolerance as
     the fp32-MFMA kernel against the CPU reference, and close to the fp32-MFMA result itself; fused statistics and the
     folded eval-mode BatchNorm go through the same epilogues."""
     from bdvcil_amd import kernels as K
@@ -140,7 +140,7 @@ def test_fprop_from_bf16_pieces(case, dev):
 @pytest.mark.parametrize('case', [c for c in CASES if c[3] % 128 == 0])
 @pytest.mark.parametrize('with_add', [False, True])
 def test_dgrad_from_bf16_pieces(case, with_add, dev):
-    """bdv_conv_dgrad_x3 (experimental) against the CPU reference and the fp32-MFMA kernel, with the residual add, the
+    """bdv_conv_dgrad_x3 (the default arithmetic) against the CPU reference and the fp32-MFMA kernel, with the residual add, the
     temporal un-shift and the stride-2 parity classes going through the unchanged epilogue."""
     from bdvcil_amd import kernels as K
     N, H, W, Cin, Cout, R, st, pad, T, fold = case
@@ -163,7 +163,7 @@ def test_dgrad_from_bf16_pieces(case, with_add, dev):
 
 @pytest.mark.parametrize('case', [c for c in CASES if c[3] % 128 == 0 and c[4] % 128 == 0])
 def test_wgrad_from_bf16_pieces(case, dev):
-    """bdv_conv_wgrad_partial_x3 (experimental) + the batched reduction against the CPU reference and the fp32-MFMA kernel."""
+    """bdv_conv_wgrad_partial_x3 (the default arithmetic) + the batched reduction against the CPU reference and the fp32-MFMA kernel."""
     from bdvcil_amd import kernels as K
     N, H, W, Cin, Cout, R, st, pad, T, fold = case
     x, w = _mk(case, 2)
@@ -177,12 +177,80 @@ def test_wgrad_from_bf16_pieces(case, dev):
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
     slab, dw3 = K.conv_wgrad_partial(dyd, xd, g, x3=True)
     K.wgrad_reduce_batched([(slab, dw3)])
-    dw1 = K.conv_wgrad(dyd, xd, g)
+    dw1 = K.conv_wgrad(dyd, xd, g, x3=False)
     _close(dw3.cpu(), ref)
     _close(dw3.cpu(), dw1.cpu(), tol=4e-6)
     slab2, dw3b = K.conv_wgrad_partial(dyd, xd, g, x3=True)
     K.wgrad_reduce_batched([(slab2, dw3b)])
     assert torch.equal(dw3, dw3b)
+
+
+def _wide_range(shape, lo, hi, gen):
+    """Random signs, exponents uniform in [lo, hi], full 24-bit significands."""
+    e = torch.randint(lo, hi + 1, shape, generator=gen).double()
+    m = 1.0 + torch.rand(shape, generator=gen, dtype=torch.float64)
+    sgn = torch.randint(0, 2, shape, generator=gen).double() * 2 - 1
+    return (sgn * m * torch.pow(torch.tensor(2.0, dtype=torch.float64), e)).float()
+
+
+@pytest.mark.parametrize('case', [(8, 7, 7, 256, 128, 1, 1, 0, 8, 32), (4, 9, 9, 128, 128, 3, 1, 1, 1, 0)])
+@pytest.mark.parametrize('regime', ['2^-60..2^60', 'denormal-adjacent'])
+def test_bf16_pieces_adversarial_range(case, regime, dev):
+    """The six-product bf16-piece arithmetic on operands that no BatchNorm-scaled tensor would produce.
+
+    '2^-60..2^60': activation exponents uniform in [-60, 60], weight exponents in [-60, 0] (products up to 2^60, no fp32
+    overflow), random signs: the pieces hi / mid / lo of every value are normal bf16 numbers.  Bar: elementwise
+    |err| <= 4e-6 * sum|a*b| against the fp64 result, the bound an fp32 FMA chain over the same K also has to meet
+    (the fp32-MFMA kernels are held to the same number on the same data).
+
+    'denormal-adjacent': activations with exponents in [-118, -108], weights near 1: the lo pieces (2^-16 relative) fall at or
+    below bf16's smallest normal number 2^-126, where the hardware may flush them.  The result may then lose the lo x hi
+    products, i.e. degrade to 2^-16 relative per product at worst: bar 4e-5 * sum|a*b| (an fp32 FMA chain keeps full
+    precision there; tensors of this magnitude do not occur on the path: activations are BatchNorm-scaled, gradients of
+    a mean loss at batch 256 are > 1e-12)."""
+    from bdvcil_amd import kernels as K
+    N, H, W, Cin, Cout, R, st, pad, T, fold = case
+    gen = torch.Generator().manual_seed(77)
+    if regime == '2^-60..2^60':
+        x = _wide_range((N, Cin, H, W), -60, 60, gen)
+        w = _wide_range((Cout, Cin, R, R), -60, 0, gen)
+        tol = {True: 4e-6, False: 4e-6}
+    else:
+        x = _wide_range((N, Cin, H, W), -118, -108, gen)
+        w = _wide_range((Cout, Cin, R, R), -1, 1, gen)
+        tol = {True: 4e-5, False: 4e-6}
+    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
+    xs = temporal_shift(x, T, Cin // fold) if fold > 0 else x
+    ref = F.conv2d(xs.double(), w.double(), stride=st, padding=pad)
+    bound = F.conv2d(xs.double().abs(), w.double().abs(), stride=st, padding=pad)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    for x3 in (True, False):
+        y = K.conv_fprop(xd, wd, g, x3=x3).cpu().permute(0, 3, 1, 2).double()
+        ratio = ((y - ref).abs() / (bound + 1e-300)).max().item()
+        assert ratio <= tol[x3], (regime, 'fprop', 'bf16x3' if x3 else 'f32mfma', ratio)
+    # dgrad and wgrad on the same operands (dy takes the activation's range)
+    wide = regime == '2^-60..2^60'
+    dy = _wide_range(tuple(ref.shape), -60, 40, gen) if wide else _wide_range(tuple(ref.shape), -118, -108, gen)
+    if not wide:        # tiny dy against activations near 1 (tiny x tiny would underflow fp32 altogether)
+        x = _wide_range((N, Cin, H, W), -1, 1, gen)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yr = F.conv2d(temporal_shift(xr, T, Cin // fold) if fold > 0 else xr, wr, stride=st, padding=pad)
+    yr.backward(dy.double())
+    xa = x.double().abs().requires_grad_(True)
+    wa = w.double().abs().requires_grad_(True)
+    F.conv2d(temporal_shift(xa, T, Cin // fold) if fold > 0 else xa, wa, stride=st, padding=pad).backward(dy.double().abs())
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    for x3 in (True, False):
+        dx = K.conv_dgrad(dyd, wd, g, x3=x3).cpu().permute(0, 3, 1, 2).double()
+        ratio = ((dx - xr.grad).abs() / (xa.grad + 1e-300)).max().item()
+        assert ratio <= tol[x3], (regime, 'dgrad', 'bf16x3' if x3 else 'f32mfma', ratio)
+        dw = K.conv_wgrad(dyd, xd, g, x3=x3).cpu().permute(0, 3, 1, 2).double()
+        ratio = ((dw - wr.grad).abs() / (wa.grad + 1e-300)).max().item()
+        # the activation / gradient products of the wide-range regime reach 2^120: sums of N*Ho*Wo of them stay below fp32 max
+        assert ratio <= tol[x3], (regime, 'wgrad', 'bf16x3' if x3 else 'f32mfma', ratio)
 
 
 def test_wgrad_partial_and_batched_reduce(dev):
@@ -212,7 +280,7 @@ def test_wgrad_partial_and_batched_reduce(dev):
         K.wgrad_reduce_batched([(items[0][0], items[1][1])])
 
 
-def test_linearity_full_size(dev):
+def test_linearity_full_size(dev, conv_arith):
     """Size-independent property at a BASELINE-size site (layer3 conv2: 256->256 3x3 on 14x14, N=256):
     conv(a*x1 + x2) == a*conv(x1) + conv(x2), and the kernel is deterministic run to run."""
     from bdvcil_amd import kernels as K
@@ -246,7 +314,7 @@ def test_bad_shapes_raise(dev):
 
 
 @pytest.mark.parametrize('shape', [(8, 14, 14, 64, 128, 1), (64, 14, 14, 256, 256, 3), (32, 28, 28, 64, 64, 3), (3, 18, 22, 4, 64, 7)])
-def test_fused_bn_statistics(shape, dev):
+def test_fused_bn_statistics(shape, dev, conv_arith):
     """BatchNorm batch statistics from the fprop epilogue (incl. K-split remainder tiles -> fix-up kernel) equal the
     column sums of the stored y, and bn_train_finalize equals torch's batch_norm statistics."""
     from bdvcil_amd import kernels as K
@@ -292,7 +360,7 @@ STAT_CASES = [
 
 @pytest.mark.parametrize('case', STAT_CASES)
 @pytest.mark.parametrize('relu', [True, False])
-def test_dgrad_fused_bn_backward_statistics(case, relu, dev):
+def test_dgrad_fused_bn_backward_statistics(case, relu, dev, conv_arith):
     from bdvcil_amd import kernels as K
     N, H, W, Cin, Cout, R, st, pad, T, fold = case
     gen = torch.Generator().manual_seed(31)
@@ -335,7 +403,7 @@ def test_dgrad_fused_bn_backward_statistics(case, relu, dev):
 
 @pytest.mark.parametrize('case', [CASES[0], CASES[2], CASES[5], CASES[8], CASES[11], (64, 14, 14, 256, 256, 3, 1, 1, 1, 0)])
 @pytest.mark.parametrize('res,relu', [(False, True), (True, True), (False, False)])
-def test_fprop_folded_eval_batchnorm(case, res, relu, dev):
+def test_fprop_folded_eval_batchnorm(case, res, relu, dev, conv_arith):
     """Eval-mode BatchNorm (+ residual) (+ ReLU) folded into the fprop epilogue == conv followed by bn_apply."""
     from bdvcil_amd import kernels as K
     N, H, W, Cin, Cout, R, st, pad, T, fold = case

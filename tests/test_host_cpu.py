@@ -79,7 +79,7 @@ def test_plugin_surface_attributes():
     with pytest.raises(AttributeError):
         bd.OutputHook(m, ['backbone.layer9'])
     hook = bd.OutputHook(m, ['backbone.layer4'])
-    pickle.loads(pickle.dumps(hook._layer_outputs['backbone.layer4']))      # picklable wrapper (ddp_spawn)
+    pickle.loads(pickle.dumps(hook.tap('backbone.layer4')))      # picklable wrapper (ddp_spawn)
     m.freeze_backbone()
     assert not any(p.requires_grad for p in m.backbone.parameters()) and m.cls_head.fc_cls.weights.requires_grad
     m.unfreeze_backbone()

@@ -15,8 +15,7 @@ from oracle import tsm_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _pair(depth, head, loss, K=11, dev=None, seed=0, nb_proxies=1):
-    import bdvcil_amd as bd
+def _oracle_only(depth, head, loss, K=11, seed=0, nb_proxies=1, want_cfg=False):
     torch.manual_seed(seed)
     cfg = O.r50_cfg(num_classes=K, depth=depth, head=head, loss=loss, dropout_ratio=0.0, nb_proxies=nb_proxies)
     ref = O.build_model(copy.deepcopy(cfg))
@@ -28,9 +27,77 @@ def _pair(depth, head, loss, K=11, dev=None, seed=0, nb_proxies=1):
             m.bias.data.normal_(0, 0.1, generator=g)
             m.running_mean.normal_(0, 0.1, generator=g)
             m.running_var.uniform_(0.5, 1.5, generator=g)
+    return (ref, cfg) if want_cfg else ref
+
+
+def _pair(depth, head, loss, K=11, dev=None, seed=0, nb_proxies=1):
+    import bdvcil_amd as bd
+    ref, cfg = _oracle_only(depth, head, loss, K, seed, nb_proxies, want_cfg=True)
     mod = bd.build_model(copy.deepcopy(cfg))
     mod.load_state_dict(ref.state_dict())
     return ref, mod.to(dev), cfg
+
+
+class ReluRecorder:
+    """Records the argument of every F.relu call of the oracle's backbone, in execution order (stem, then per block:
+    conv1, [conv2,] block output).  The oracle calls ``F.relu`` through its module-level ``F`` (oracle/tsm_oracle.py)."""
+
+    class _Proxy:
+        def __init__(self, real, sink):
+            self._real, self._sink = real, sink
+
+        def relu(self, x, *a, **kw):
+            if x.dim() == 4:
+                self._sink.append(x.detach())
+            return self._real.relu(x, *a, **kw)
+
+        def __getattr__(self, name):
+            return getattr(self._real, name)
+
+    def __enter__(self):
+        self.pre, self._saved = [], O.F
+        O.F = ReluRecorder._Proxy(self._saved, self.pre)
+        return self
+
+    def __exit__(self, *exc):
+        O.F = self._saved
+        return False
+
+
+def relu_site_owners(ref):
+    """Parameter-name prefixes of the conv+BN units whose output feeds each recorded ReLU, in the recorder's order."""
+    sites = [['backbone.conv1.']]
+    for li in range(1, 5):
+        for bi, blk in enumerate(getattr(ref.backbone, f'layer{li}')):
+            pre = f'backbone.layer{li}.{bi}.'
+            names = [n for n in ('conv1', 'conv2', 'conv3') if hasattr(blk, n)]
+            for n in names[:-1]:
+                sites.append([pre + n + '.'])
+            sites.append([pre + names[-1] + '.', pre + 'downsample.'])
+    return sites
+
+
+def count_relu_flips(pre64, taps):
+    """Per ReLU site: number of elements whose sign bit in the HIP mask differs from the fp64 oracle's ``pre > 0``; every
+    such element must be one the oracle itself places within 1e-5 of its channel's largest magnitude of zero
+    (the fp32 CPU oracle's own pre-activations deviate from the fp64 ones by up to 2e-5 channel standard deviations)."""
+    assert len(pre64) == len(taps), (len(pre64), len(taps))
+    flips = []
+    for k, (pre, (shape, mask)) in enumerate(zip(pre64, taps)):
+        N, H, W, C = shape
+        assert tuple(pre.shape) == (N, C, H, W), (k, tuple(pre.shape), shape)
+        bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder='little').astype(bool).reshape(N, H, W, C)
+        want = (pre > 0).permute(0, 2, 3, 1).numpy()
+        diff = torch.from_numpy(bits != want)
+        n = int(diff.sum())
+        if n:
+            rel = (pre.abs() / pre.abs().amax(dim=(0, 2, 3), keepdim=True)).permute(0, 2, 3, 1)[diff]
+            assert float(rel.max()) <= 1e-5, f'ReLU site {k}: a sign differs where the fp64 pre-activation is {float(rel.max()):.2e} of its channel max'
+        flips.append(n)
+    return flips
+
+
+FLIP_FREE_SEED = 25     # chosen with tools/find_flip_free_seed.py (see test_train_step)
 
 
 def _clips(B, T, S, K, seed=0):
@@ -54,7 +121,7 @@ def _rel_l2(a, b):
 
 
 @pytest.mark.parametrize('depth,S', [(18, 64), (34, 64), (50, 64), (50, 224)])
-def test_eval_logits(depth, S, dev):
+def test_eval_logits(depth, S, dev, conv_arith):
     ref, mod, _ = _pair(depth, 'LocalSimilarityClassifier', 'LSCLoss', dev=dev)
     imgs, _ = _clips(2, 8, S, 11)
     ref.eval(); mod.eval()
@@ -68,32 +135,58 @@ def test_eval_logits(depth, S, dev):
             assert torch.equal(o.argmax(1), r.argmax(1))
 
 
-@pytest.mark.parametrize('depth,head,loss,S,B', [
-    (18, 'LocalSimilarityClassifier', 'LSCLoss', 224, 4),      # BASELINE config 1 (R18, B=4)
-    (34, 'LocalSimilarityClassifier', 'LSCLoss', 64, 2),
-    (50, 'SimpleLinear', 'CrossEntropyLoss', 64, 2),
-    (50, 'LocalSimilarityClassifier', 'LSCLoss', 224, 2),
+@pytest.mark.parametrize('depth,head,loss,S,B,clip_seed', [
+    (18, 'LocalSimilarityClassifier', 'LSCLoss', 224, 4, 0),      # BASELINE config 1 (R18, B=4)
+    (18, 'LocalSimilarityClassifier', 'LSCLoss', 64, 2, FLIP_FREE_SEED),   # no activation of the fp64 oracle within 1e-6 std of 0
+    (34, 'LocalSimilarityClassifier', 'LSCLoss', 64, 2, 0),
+    (50, 'SimpleLinear', 'CrossEntropyLoss', 64, 2, 0),
+    (50, 'LocalSimilarityClassifier', 'LSCLoss', 224, 2, 0),
 ])
-def test_train_step(depth, head, loss, S, B, dev):
+def test_train_step(depth, head, loss, S, B, clip_seed, dev, conv_arith):
     """Loss / accuracies / every parameter gradient / BN statistics / one clipped SGD step.
-    Gradients are judged against the fp64 run of the oracle: the HIP path must be no further from it than
-    3x the fp32 CPU oracle is (plus a 1e-2 relative-L2 floor for rare ReLU-mask flips) -- i.e. within the reference's own rounding noise."""
+
+    Gradients are judged against the fp64 run of the oracle.  Train-mode BN + ReLU is discontinuous: an activation that the
+    fp64 oracle places within ~1e-6 of zero can take the other branch in any fp32 implementation (the fp32 CPU oracle does
+    it too), and one flipped element moves its channel's gradient by per cents.  So the ReLU sign bits the HIP path wrote
+    are read back and compared with the oracle's: every difference must sit where the fp64 pre-activation is within 1e-5
+    of its channel's scale (largest magnitude) of zero, and
+      * parameters that no flipped ReLU lies behind (in backward order) are held to  relL2 <= 3 * e_f32 + 1e-4,
+      * parameters upstream of a counted flip keep the looser  3 * e_f32 + 1e-2."""
     import bdvcil_amd as bd
+    from bdvcil_amd import functional as Fn
     K = 11
     ref, mod, _ = _pair(depth, head, loss, K=K, dev=dev)
     ref64 = copy.deepcopy(ref).double()
-    imgs, labels = _clips(B, 8, S, K)
+    imgs, labels = _clips(B, 8, S, K, seed=clip_seed)
     ref.train(); mod.train(); ref64.train()
     rl = ref(imgs, labels)
     rl['loss_cls'].backward()
-    r64 = ref64(imgs.double(), labels)
+    with ReluRecorder() as rec:
+        r64 = ref64(imgs.double(), labels)
     r64['loss_cls'].backward()
-    ol = mod(imgs.to(dev), labels.to(dev), batch_data=None)
+    Fn.RELU_MASK_TAP = taps = []
+    try:
+        ol = mod(imgs.to(dev), labels.to(dev), batch_data=None)
+    finally:
+        Fn.RELU_MASK_TAP = None
     ol['loss_cls'].backward()
     assert abs(ol['loss_cls'].item() - rl['loss_cls'].item()) <= 1e-4 * max(1.0, abs(rl['loss_cls'].item()))
     assert abs(ol['top1_acc'].item() - rl['top1_acc'].item()) < 1e-6
     assert abs(ol['top5_acc'].item() - rl['top5_acc'].item()) < 1e-6
+    flips = count_relu_flips(rec.pre, taps)
+    owners = relu_site_owners(ref)
+    assert len(owners) == len(flips)
+    last_flip = max([k for k, n in enumerate(flips) if n], default=-1)
+    print(f'\n[relu flips] R{depth} S={S} B={B} {conv_arith}: {sum(flips)} of {sum(p.numel() for p in rec.pre)} signs differ '
+          f'from the fp64 oracle, sites {[k for k, n in enumerate(flips) if n]}')
+
+    def behind_a_flip(name):           # a flip at site k perturbs the gradients of every unit up to and including site k
+        for k, prefixes in enumerate(owners):
+            if any(name.startswith(q) for q in prefixes):
+                return k <= last_flip
+        return False                   # head / loss parameters: after every ReLU of the backbone
     rp, r64p, op = dict(ref.named_parameters()), dict(ref64.named_parameters()), dict(mod.named_parameters())
+    worst = {}
     for name, p in rp.items():
         if p.grad is None:
             assert op[name].grad is None or op[name].grad.abs().max().item() == 0, name
@@ -101,7 +194,12 @@ def test_train_step(depth, head, loss, S, B, dev):
         assert op[name].grad is not None, name
         e_hip = _rel_l2(op[name].grad, r64p[name].grad)
         e_f32 = _rel_l2(p.grad, r64p[name].grad)
-        assert e_hip <= 3 * e_f32 + 1e-2, (name, e_hip, e_f32)
+        loose = behind_a_flip(name)
+        floor = 1e-2 if loose else 1e-4
+        assert e_hip <= 3 * e_f32 + floor, (name, e_hip, e_f32, 'behind a flipped ReLU' if loose else 'no flip behind it', flips)
+        if e_hip > worst.get(loose, (0,))[0]:
+            worst[loose] = (e_hip, e_f32, name)
+    print(f'[grad parity] worst strict: {worst.get(False)}  worst behind a flip: {worst.get(True)}')
     # BN running statistics
     rb, ob = dict(ref.named_buffers()), dict(mod.named_buffers())
     for name, b in rb.items():

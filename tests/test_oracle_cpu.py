@@ -112,6 +112,55 @@ def test_r50_parameter_count_matches_metafile():
     assert n_backbone == 23508032 and n_backbone + n_head == 24327632
 
 
+def test_r50_flop_count_matches_metafile():
+    """configs/recognition/tsm/metafile.yml:14 (FLOPs: 32965562368 for tsm_r50_1x1x8 at 8 x 224 x 224, K = 400), the only
+    other backbone fact the reference tree holds.  The figure is mmcv's ``get_model_complexity_info`` count: conv MACs +
+    2 per BatchNorm element + 1 per ReLU element + max-/avg-pool input elements + classifier MACs.  The oracle's layer
+    shapes, its BatchNorm and ReLU placement and the head reproduce it exactly: 32 697 090 048 conv MACs (= 8 x 4.0871 G,
+    SURVEY Appendix B, the figure bench.py's algorithmic FLOP are built on) + 177 823 744 + 76 869 632 + 7 225 344 + 6 553 600."""
+    import torch.nn as nn
+    m = O.build_model(O.r50_cfg(num_classes=400, depth=50, head='SimpleLinear', loss='CrossEntropyLoss'))
+    m.eval()
+    cnt = dict(conv=0, bn=0, relu=0, pool=0)
+
+    def conv_h(mod, i, o):
+        cnt['conv'] += o.numel() * mod.in_channels * mod.kernel_size[0] * mod.kernel_size[1]
+
+    def bn_h(mod, i, o):
+        cnt['bn'] += 2 * i[0].numel()
+
+    def pool_h(mod, i, o):
+        cnt['pool'] += i[0].numel()
+
+    class _F:                                   # the oracle applies ReLU through its module-level ``F``
+        def __init__(self, real):
+            self._real = real
+
+        def relu(self, x, *a, **kw):
+            cnt['relu'] += x.numel() if x.dim() == 4 else 0
+            return self._real.relu(x, *a, **kw)
+
+        def __getattr__(self, name):
+            return getattr(self._real, name)
+
+    for x in m.modules():
+        if isinstance(x, nn.Conv2d):
+            x.register_forward_hook(conv_h)
+        elif isinstance(x, nn.BatchNorm2d):
+            x.register_forward_hook(bn_h)
+        elif isinstance(x, nn.MaxPool2d):
+            x.register_forward_hook(pool_h)
+    real, O.F = O.F, _F(O.F)
+    try:
+        with torch.no_grad():
+            m(torch.zeros(1, 8, 3, 224, 224), return_loss=False)
+    finally:
+        O.F = real
+    avgpool, fc = 8 * 2048 * 7 * 7, 8 * 2048 * 400
+    assert cnt['conv'] == 32697090048
+    assert cnt['conv'] + cnt['bn'] + cnt['relu'] + cnt['pool'] + avgpool + fc == 32965562368
+
+
 def test_bgmix_formula():
     g = torch.Generator().manual_seed(0)
     fr = torch.randint(0, 256, (2, 3, 5, 6, 3), generator=g, dtype=torch.uint8)

@@ -193,6 +193,6 @@ def test_cbf_phase_and_icarl(tmp_path):
     cfg = _config(tmp_path / 'b', methods='icarl', ending_task=1, num_epochs_per_task=1)
     cfg['model']['cls_head']['inc_head_config'] = dict(type='SimpleLinear', out_features=2)
     cfg['model']['cls_head']['loss_cls'] = dict(type='CrossEntropyLoss')
-    cfg['model']['test_cfg'] = dict(average_clips='score')
+    # the shipped iCaRL configs say average_clips='prob' (kept here); the loop switches both models to 'score' (icarl.py:34,39)
     hist = _loop(cfg).train()
     assert len(hist) == 2 and all(np.isfinite(h['train_loss']).all() for h in hist)
