@@ -1,14 +1,16 @@
 #!/usr/bin/env python
 """Headline benchmark: clips/s, forward + backward + fused SGD step, TSM-ResNet50, 8x3x224x224 clips,
-batch 32 per GPU, fp32 (BASELINE.json configs[1]; synthetic clips, random-init weights).
+batch 32 per GPU, fp32 tensors and results (BASELINE.json configs[1]; synthetic clips, random-init weights).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...            # N > 1 without a launcher: starts torch.distributed.run itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-``roofline`` (dominant kernel = the fp32-MFMA implicit-GEMM conv; algorithmic FLOP / HIP-event time measured
-inside the timed region) and ``cpu_baseline`` (the CPU oracle timed on this box's host cores, N=1 only).
+``roofline`` (dominant kernel = an implicit-GEMM conv kernel; algorithmic FLOP / HIP-event time measured inside the timed
+region, priced against the peak of the MFMA instruction it issues) and ``cpu_baseline`` (the CPU oracle timed on this
+box's host cores, N=1 only).
 """
 import argparse
 import copy
@@ -28,6 +30,11 @@ R50_FLOP_PER_CLIP = 194.29e9       # BASELINE.md section 2 (fwd+bwd, conv MACs o
 R50_KD_FLOP_PER_CLIP = 259.7e9     # + the frozen previous model's forward
 R50_FWD_FLOP_PER_CLIP = 65.39e9    # forward only (2 x 8 x 4.0871 GMAC)
 PEAK_F32_MFMA = 157.3e12           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+PEAK_BF16_MFMA = 2516.6e12         # v_mfma_f32_32x32x16_bf16: 32 cycles per 32x32x16 on 1024 SIMDs at 2.4 GHz, dense
+# An fp32 product formed from three bf16 pieces per operand costs six bf16 MFMA products: the MFMA-bound rate of the
+# default conv kernels in fp32-equivalent FLOP (2*M*N*K per GEMM) is the bf16 dense peak / 6.
+PEAK_BF16X3 = PEAK_BF16_MFMA / 6.0
+PROFILE_ROUND = 'r02'
 
 
 def model_cfg(depth, num_classes, head, loss, dropout):
@@ -44,7 +51,10 @@ def model_cfg(depth, num_classes, head, loss, dropout):
 
 
 class ConvTimer:
-    """HIP-event timing of every conv launch on the stream it is launched on (torch's current stream)."""
+    """HIP-event timing of every conv launch on the stream it is launched on (torch's current stream).  An event pair
+    spans one C-ABI call: the main kernel plus its K-split fix-up when the planner uses one.  The weight-gradient main
+    kernels (``conv_wgrad_partial``) and their batched split-K reduction (``wgrad_reduce_batched``, one launch per stage)
+    are separate calls and separate lines."""
 
     def __init__(self):
         self.records = []      # (tag, flops, start_event, end_event)
@@ -53,34 +63,64 @@ class ConvTimer:
     def wrap(self, K):
         timer = self
 
-        def kernel_tag(kind, g):
+        def kernel_tag(kind, g, x3):
             if kind == 'fprop':
                 if g.Cin == 4:
                     return 'conv_fprop_c4_kernel<128,64,2,2>'
-                return 'conv_fprop_kernel<128,128,2,2>' if g.Cout % 128 == 0 else 'conv_fprop_kernel<128,64,2,2>'
+                if g.Cout % 128 == 0:
+                    return 'conv_fprop_x3_kernel<128,128,2,2>' if x3 else 'conv_fprop_kernel<128,128,2,2>'
+                return 'conv_fprop_kernel<128,64,2,2>'
             if kind == 'dgrad':
-                return 'conv_dgrad_kernel<128,128,2,2>' if g.Cin % 128 == 0 else 'conv_dgrad_kernel<128,64,2,2>'
+                if g.Cin % 128 == 0:
+                    return 'conv_dgrad_x3_kernel<128,128,2,2>' if x3 else 'conv_dgrad_kernel<128,128,2,2>'
+                return 'conv_dgrad_kernel<128,64,2,2>'
             small = (g.Cin % 32 != 0) or (g.Cout % 128 != 0) or (g.Cin % 128 != 0)
-            return 'conv_wgrad_kernel<64,64,2,2>' if small else 'conv_wgrad_kernel<128,128,2,2>'
+            if small:
+                return 'conv_wgrad_kernel<64,64,2,2>'
+            return 'conv_wgrad_x3_kernel<128,128,2,2>' if x3 else 'conv_wgrad_kernel<128,128,2,2>'
 
-        def make(kind, fn, geom_pos):
+        def make(kind, fn, geom_pos, flag):
             def timed(*a, **kw):
                 if not timer.enabled:
                     return fn(*a, **kw)
                 g = a[geom_pos]
+                x3 = kw.get('x3')
+                x3 = getattr(K, flag) if x3 is None else x3
                 cin = 3 if g.Cin == 4 else g.Cin
                 flops = 2.0 * g.N * g.Ho * g.Wo * g.Cout * g.R * g.S * cin
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 out = fn(*a, **kw)
                 e1.record()
-                timer.records.append((kernel_tag(kind, g), flops, e0, e1))
+                timer.records.append((kernel_tag(kind, g, x3), flops, e0, e1))
                 return out
             return timed
 
-        K.conv_fprop = make('fprop', K.conv_fprop, 2)
-        K.conv_dgrad = make('dgrad', K.conv_dgrad, 2)
-        K.conv_wgrad = make('wgrad', K.conv_wgrad, 2)
+        def timed_reduce(fn):
+            def timed(*a, **kw):
+                if not timer.enabled:
+                    return fn(*a, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = fn(*a, **kw)
+                e1.record()
+                timer.records.append(('wgrad_reduce_batched_kernel', 0.0, e0, e1))
+                return out
+            return timed
+
+        K.conv_fprop = make('fprop', K.conv_fprop, 2, 'FPROP_X3')
+        K.conv_dgrad = make('dgrad', K.conv_dgrad, 2, 'DGRAD_X3')
+        # conv_wgrad (one-call form: the stem) runs the same main kernels; with the bf16-piece arithmetic it goes through
+        # conv_wgrad_partial + wgrad_reduce_batched, which are timed below, so it is only wrapped for the fp32-MFMA path
+        inner_wgrad = K.conv_wgrad
+        timed_wgrad = make('wgrad', inner_wgrad, 2, 'WGRAD_X3')
+
+        def conv_wgrad(*a, **kw):
+            x3 = kw.get('x3')
+            return inner_wgrad(*a, **kw) if (K.WGRAD_X3 if x3 is None else x3) else timed_wgrad(*a, **kw)
+        K.conv_wgrad = conv_wgrad
+        K.conv_wgrad_partial = make('wgrad', K.conv_wgrad_partial, 2, 'WGRAD_X3')
+        K.wgrad_reduce_batched = timed_reduce(K.wgrad_reduce_batched)
 
     def summary(self):
         by = {}
@@ -95,9 +135,9 @@ class ConvTimer:
 
 def pmc_traffic(tag):
     """HBM-side bytes per launch of kernel ``tag`` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r01_traffic.json, produced by tools/run_profile.sh + tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
+    (profiles/<round>_traffic.json, produced by tools/run_profile.sh + tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in
     separate passes, KiB units, FETCH_SIZE doubled on gfx950).  None when the file has no entry."""
-    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    path = os.path.join(ROOT, 'profiles', f'{PROFILE_ROUND}_traffic.json')
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -108,6 +148,25 @@ def pmc_traffic(tag):
         if n == want or n.startswith(want[:-1] + ','):      # wgrad carries two more template flags
             return v.get('hbm_bytes_per_launch')
     return None
+
+
+def rocprof_avg_us(tag):
+    """Average duration (us) of kernel ``tag`` in the committed ``rocprofv3 --kernel-trace --stats`` summary of this same
+    command (profiles/<round>_kernel_stats.csv); None when absent.  Reported beside the live HIP-event time."""
+    import csv
+    path = os.path.join(ROOT, 'profiles', f'{PROFILE_ROUND}_kernel_stats.csv')
+    if not os.path.exists(path):
+        return None
+    want = tag.replace(' ', '')
+    tot_ns, calls = 0.0, 0
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            n = row['Name'].replace(' ', '')
+            k = n.find(want[:-1])
+            if k >= 0 and n[k + len(want) - 1] in '>,':
+                tot_ns += float(row['TotalDurationNs'])
+                calls += int(row['Calls'])
+    return round(tot_ns / calls / 1e3, 2) if calls else None
 
 
 def cpu_baseline(depth, num_classes, head, loss, budget_s=25.0):
@@ -141,6 +200,40 @@ def cpu_baseline(depth, num_classes, head, loss, budget_s=25.0):
                        f'(torch {torch.__version__} CPU, fp32)')
 
 
+def self_launch(n, argv):
+    """``python bench.py --gpus N`` without torchrun: run ``torch.distributed.run`` with N ranks on 127.0.0.1 as a child
+    process (this process never initialises the GPU), pass the child's output through and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: required by RCCL on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
+def selftest_cpu(args, world, rank):
+    """What the ranks started by ``self_launch`` do in the CPU test of the launcher: the rendezvous, the barrier-bracketed
+    timing with the MAX over ranks, and rank 0 printing the one line -- over gloo, with no GPU and no kernels."""
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    x = torch.ones(4) * (rank + 1)
+    dist.all_reduce(x)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({'metric': 'launcher selftest', 'value': float(x[0]), 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': float(t) * 1e3}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -158,15 +251,23 @@ def main():
                          "+ representations of BaseCIL.predict_step (SURVEY section 8(f) rank 1), no backward")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--no-experimental', action='store_true',
-                    help='skip the extra, separately reported run with the bf16-piece K loops switched on (DESIGN.md section 8)')
+    ap.add_argument('--arith', default='bf16x3', choices=['bf16x3', 'f32mfma'],
+                    help="conv arithmetic: 'bf16x3' (default; fp32 products from three bf16 pieces per operand, six bf16 MFMA "
+                         "products, fp32 accumulate) or 'f32mfma' (v_mfma_f32_32x32x2_f32 kernels)")
+    ap.add_argument('--selftest-cpu', action='store_true', help=argparse.SUPPRESS)   # launcher test: gloo ranks, no GPU
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # Started without a launcher: this process has not touched the GPU (importing torch does not), so it may start
+        # one fresh process per GPU -- what the reference's ddp_spawn does (libs/cil/cil.py:704-709) -- and relay rank 0's line.
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks')
+    if args.selftest_cpu:
+        return selftest_cpu(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
@@ -182,6 +283,7 @@ def main():
     import bdvcil_amd as bd
     from bdvcil_amd import kernels as K
 
+    K.set_conv_arith(args.arith)
     timer = ConvTimer()
     if not args.no_kernel_timing:
         timer.wrap(K)
@@ -260,31 +362,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # Reported beside the metric, never as it: the same K steps with the experimental conv K loops that form every fp32
-    # product from three bf16 pieces per operand (bdv_conv_*_x3).  `value` above is the fp32-MFMA path.
-    dtx = None
-    if not args.no_experimental and not (K.FPROP_X3 or K.DGRAD_X3 or K.WGRAD_X3):
-        K.FPROP_X3 = K.DGRAD_X3 = K.WGRAD_X3 = True
-        try:
-            timer.enabled = False
-            for _ in range(min(args.warmup, 3)):
-                engine.step(batch, loss_fn)
-            sync()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                engine.step(batch, loss_fn)
-            sync()
-            dtx = time.perf_counter() - t0
-            if use_dist:
-                t = torch.tensor([dtx], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dtx = float(t.item())
-        except Exception as e:      # the metric above must be reported whatever happens in the side measurement
-            print(f'[bench] experimental run failed: {e!r}', file=sys.stderr, flush=True)
-            dtx = None
-        finally:
-            K.FPROP_X3 = K.DGRAD_X3 = K.WGRAD_X3 = False
-
     if rank == 0:
         clips = args.batch * world * args.steps
         value = clips / dt
@@ -298,41 +375,47 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': ('CIL task-1 step (uint8 bg-mix front-end, frozen teacher forward, 5 feature-KD MSE terms, clip 1.0): ' if cil else '')
                                    + f'TSM-ResNet{args.depth} ' + ('eval forward + clip representations (predict_step)' if predict else 'fwd+bwd+SGD step') + f', synthetic {args.batch}x8x3x224x224 clips per GPU, '
-                                   f'{args.classes} classes, {args.head}+{args.loss}, dropout {args.dropout}, random-init weights',
+                                   f'{args.classes} classes, {args.head}+{args.loss}, dropout {args.dropout}, random-init weights; '
+                                   + ('fp32 tensors, accumulators and results; conv products: fp32 via 3xbf16 split, 6 MFMA products, fp32 accumulate '
+                                      '(dropped terms <= 2^-24 relative)' if args.arith == 'bf16x3' else
+                                      'fp32 tensors and results; conv products on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)'),
+                       'conv_arith': args.arith,
                        'clips_per_gpu': args.batch, 'global_batch': args.batch * world, 'parallelism': f'dp{world}',
                        'final_loss': round(loss_val, 5)},
         }
         if flop_per_clip:
             res['config']['algorithmic_flop_per_clip'] = flop_per_clip
+            res['config']['step_tflops'] = round(value / world * flop_per_clip / 1e12, 2)
             res['config']['step_frac_of_f32_mfma_peak'] = round(value / world * flop_per_clip / PEAK_F32_MFMA, 4)
         if not args.no_kernel_timing and timer.records:
             by = timer.summary()
             timed_steps = (args.steps + 3) // 4
-            dom = max(by, key=lambda k: by[k]['ms'])
-            d = by[dom]
+            conv = {k: v for k, v in by.items() if v['flops'] > 0}
+            dom = max(conv, key=lambda k: conv[k]['ms'])
+            d = conv[dom]
+            peak = PEAK_BF16X3 if '_x3_' in dom else PEAK_F32_MFMA
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
             tot_ms = sum(v['ms'] for v in by.values())
             tot_fl = sum(v['flops'] for v in by.values())
             res['roofline'] = {
-                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(PEAK_F32_MFMA / 1e12, 1), 'unit': 'TFLOP/s',
-                'frac': round(achieved * 1e12 / PEAK_F32_MFMA, 4), 'traffic': pmc_traffic(dom),
-                'traffic_note': 'HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of '
-                                'this command, profiles/r01_traffic.json); avg_launch_ms spans the whole C-ABI call '
-                                '(main kernel + its K-split fix-up / slab reduce when the planner uses one)',
+                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak / 1e12, 1), 'unit': 'TFLOP/s',
+                'frac': round(achieved * 1e12 / peak, 4), 'traffic': pmc_traffic(dom),
+                'peak_note': ('fp32-equivalent FLOP (2*M*N*K) against the bf16 dense MFMA peak / 6: every fp32 product costs six '
+                              'v_mfma_f32_32x32x16_bf16 products' if '_x3_' in dom else 'v_mfma_f32_32x32x2_f32 dense peak'),
+                'frac_of_f32_mfma_peak': round(achieved * 1e12 / PEAK_F32_MFMA, 4),
+                'traffic_note': f'HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of '
+                                f'this command, profiles/{PROFILE_ROUND}_traffic.json); avg_launch_ms spans the whole C-ABI call '
+                                '(main kernel + its K-split fix-up when the planner uses one)',
                 'kernel': dom, 'launches_per_step': d['launches'] // timed_steps,
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+                'rocprof_avg_us': rocprof_avg_us(dom),
                 'algorithmic_gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 2),
                 'all_conv_kernels': {k: {'launches_per_step': v['launches'] // timed_steps, 'ms_per_step': round(v['ms'] / timed_steps, 3),
-                                         'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in sorted(by.items())},
+                                         'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['flops'] else None,
+                                         'rocprof_avg_us': rocprof_avg_us(k)} for k, v in sorted(by.items())},
                 'conv_ms_per_step': round(tot_ms / timed_steps, 3), 'conv_tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                 'kernel_timed_steps': timed_steps,
             }
-        if dtx is not None:
-            res['experimental_bf16_pieces'] = {
-                'value': round(clips / dtx, 2), 'unit': 'clips/s', 'ms_per_step': round(1000.0 * dtx / args.steps, 3),
-                'note': 'NOT the metric: same steps with BDVCIL_FPROP_X3 / DGRAD_X3 / WGRAD_X3 (fp32 products from three bf16 '
-                        'pieces per operand, six bf16 MFMAs per K-step, fp32 accumulate; error at the level of an fp32 FMA chain, '
-                        'DESIGN.md section 8); off by default'}
         if world == 1 and not args.no_cpu_baseline and not cil and not predict:
             res['cpu_baseline'] = cpu_baseline(args.depth, args.classes, args.head, args.loss)
         print(json.dumps(res), flush=True)

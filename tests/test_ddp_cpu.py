@@ -108,3 +108,26 @@ def test_tail_bucket_split():
     r = bd.GradAllReducer(model, bucket_cap_mb=25.0, tail_cap_mb=0.001)           # nothing fits the tail: unchanged
     assert len(r.buckets) == 1
     r.remove()
+
+
+def test_bench_self_launch_without_torchrun():
+    """``python bench.py --gpus 2`` with no WORLD_SIZE in the environment starts its own ranks (the driver's N = 1 command
+    line is a plain ``python bench.py``; the N > 1 record must not depend on an outer launcher).  The ranks run the
+    launcher self-test: gloo rendezvous on 127.0.0.1, barrier-bracketed timing, MAX over ranks, one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--selftest-cpu'], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['value'] == 3.0 and rec['steps'] == 3      # all-reduce over both ranks: 1 + 2
+    # a launcher that starts the wrong number of ranks is refused
+    env2 = dict(env, WORLD_SIZE='3', RANK='0', LOCAL_RANK='0')
+    bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--selftest-cpu'], env=env2,
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and 'WORLD_SIZE=3' in (bad.stderr + bad.stdout)

@@ -1,10 +1,15 @@
+# Round profile of the bench command (run on the GPU box through gpurun): bench line, rocprofv3 kernel stats, and the two
+# PMC passes (FETCH_SIZE / WRITE_SIZE separately, without any trace domain, as the MI355X guide prescribes).
+#   R=r02 bash tools/run_profile.sh        -> gpurun_out/$R/{bench.json,stats/,traffic.json}
 set -e
+R=${R:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r01
-timeout -k 10 300 python bench.py > gpurun_out/r01/bench.json 2> gpurun_out/r01/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-experimental > gpurun_out/r01/stats_bench.json 2> gpurun_out/r01/stats.err
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r01/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-experimental > gpurun_out/r01/pmc_fetch.json 2> gpurun_out/r01/pmc_fetch.err
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/r01/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-experimental > gpurun_out/r01/pmc_write.json 2> gpurun_out/r01/pmc_write.err
-python tools/pmc_traffic.py gpurun_out/r01/pmc_fetch gpurun_out/r01/pmc_write > gpurun_out/r01/traffic.json
-find gpurun_out/r01 -name "*counter_collection.csv" -size +8M -delete
-ls -la gpurun_out/r01 gpurun_out/r01/stats/* | head -40
+mkdir -p gpurun_out/$R
+timeout -k 10 400 python bench.py > gpurun_out/$R/bench.json 2> gpurun_out/$R/bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/$R/stats_bench.json 2> gpurun_out/$R/stats.err
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$R/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > gpurun_out/$R/pmc_fetch.json 2> gpurun_out/$R/pmc_fetch.err
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/$R/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > gpurun_out/$R/pmc_write.json 2> gpurun_out/$R/pmc_write.err
+python tools/pmc_traffic.py gpurun_out/$R/pmc_fetch gpurun_out/$R/pmc_write > gpurun_out/$R/traffic.json
+find gpurun_out/$R -name "*counter_collection.csv" -size +8M -delete
+find gpurun_out/$R -name "*kernel_trace.csv" -size +8M -delete
+ls -la gpurun_out/$R gpurun_out/$R/stats/* | head -40
