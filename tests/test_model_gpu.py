@@ -77,24 +77,41 @@ def relu_site_owners(ref):
     return sites
 
 
-def count_relu_flips(pre64, taps):
-    """Per ReLU site: number of elements whose sign bit in the HIP mask differs from the fp64 oracle's ``pre > 0``; every
-    such element must be one the oracle itself places within 1e-5 of its channel's largest magnitude of zero
-    (the fp32 CPU oracle's own pre-activations deviate from the fp64 ones by up to 2e-5 channel standard deviations)."""
-    assert len(pre64) == len(taps), (len(pre64), len(taps))
-    flips = []
-    for k, (pre, (shape, mask)) in enumerate(zip(pre64, taps)):
+def _report(line):
+    """Parity figures of passing tests are kept (pytest -q hides prints): appended to gpurun_out/parity_report.log."""
+    import os
+    print(line)
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, 'parity_report.log'), 'a') as f:
+            f.write(line.strip() + '\n')
+
+
+def count_relu_flips(pre64, pre32, taps):
+    """Per ReLU site: number of elements whose sign bit in the HIP mask differs from the fp64 oracle's ``pre > 0``.
+    A difference is legitimate only where fp32 rounding can reach zero: the fp64 pre-activation must lie within
+    max(1e-5, 3 x the largest deviation of the fp32 CPU oracle's own pre-activations at that site) of zero, both measured
+    in units of the channel's largest magnitude (the CPU oracle's deviation grows with depth: ~2e-6 at the stem, ~2e-5
+    behind 40 conv+BN layers).  Returns (flips per site, flips of the fp32 CPU oracle per site)."""
+    assert len(pre64) == len(taps) == len(pre32), (len(pre64), len(pre32), len(taps))
+    flips, flips32 = [], []
+    for k, (pre, p32, (shape, mask)) in enumerate(zip(pre64, pre32, taps)):
         N, H, W, C = shape
         assert tuple(pre.shape) == (N, C, H, W), (k, tuple(pre.shape), shape)
         bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder='little').astype(bool).reshape(N, H, W, C)
         want = (pre > 0).permute(0, 2, 3, 1).numpy()
         diff = torch.from_numpy(bits != want)
         n = int(diff.sum())
+        cmax = pre.abs().amax(dim=(0, 2, 3), keepdim=True)
+        noise32 = float(((p32.double() - pre).abs() / cmax).max())
+        flips32.append(int(((p32 > 0) != (pre > 0)).sum()))
         if n:
-            rel = (pre.abs() / pre.abs().amax(dim=(0, 2, 3), keepdim=True)).permute(0, 2, 3, 1)[diff]
-            assert float(rel.max()) <= 1e-5, f'ReLU site {k}: a sign differs where the fp64 pre-activation is {float(rel.max()):.2e} of its channel max'
+            rel = (pre.abs() / cmax).permute(0, 2, 3, 1)[diff]
+            bar = max(1e-5, 3 * noise32)
+            assert float(rel.max()) <= bar, (f'ReLU site {k}: a sign differs where the fp64 pre-activation is {float(rel.max()):.2e} of '
+                                              f'its channel max (fp32 CPU oracle deviates by up to {noise32:.2e} there)')
         flips.append(n)
-    return flips
+    return flips, flips32
 
 
 FLIP_FREE_SEED = 25     # chosen with tools/find_flip_free_seed.py (see test_train_step)
@@ -159,7 +176,8 @@ def test_train_step(depth, head, loss, S, B, clip_seed, dev, conv_arith):
     ref64 = copy.deepcopy(ref).double()
     imgs, labels = _clips(B, 8, S, K, seed=clip_seed)
     ref.train(); mod.train(); ref64.train()
-    rl = ref(imgs, labels)
+    with ReluRecorder() as rec32:
+        rl = ref(imgs, labels)
     rl['loss_cls'].backward()
     with ReluRecorder() as rec:
         r64 = ref64(imgs.double(), labels)
@@ -173,12 +191,13 @@ def test_train_step(depth, head, loss, S, B, clip_seed, dev, conv_arith):
     assert abs(ol['loss_cls'].item() - rl['loss_cls'].item()) <= 1e-4 * max(1.0, abs(rl['loss_cls'].item()))
     assert abs(ol['top1_acc'].item() - rl['top1_acc'].item()) < 1e-6
     assert abs(ol['top5_acc'].item() - rl['top5_acc'].item()) < 1e-6
-    flips = count_relu_flips(rec.pre, taps)
+    flips, flips32 = count_relu_flips(rec.pre, rec32.pre, taps)
     owners = relu_site_owners(ref)
     assert len(owners) == len(flips)
     last_flip = max([k for k, n in enumerate(flips) if n], default=-1)
-    print(f'\n[relu flips] R{depth} S={S} B={B} {conv_arith}: {sum(flips)} of {sum(p.numel() for p in rec.pre)} signs differ '
-          f'from the fp64 oracle, sites {[k for k, n in enumerate(flips) if n]}')
+    _report(f'[relu flips] R{depth} S={S} B={B} {conv_arith}: {sum(flips)} of {sum(p.numel() for p in rec.pre)} signs differ '
+            f'from the fp64 oracle at sites {[k for k, n in enumerate(flips) if n]} (fp32 CPU oracle: {sum(flips32)} at '
+            f'{[k for k, n in enumerate(flips32) if n]})')
 
     def behind_a_flip(name):           # a flip at site k perturbs the gradients of every unit up to and including site k
         for k, prefixes in enumerate(owners):
@@ -199,7 +218,8 @@ def test_train_step(depth, head, loss, S, B, clip_seed, dev, conv_arith):
         assert e_hip <= 3 * e_f32 + floor, (name, e_hip, e_f32, 'behind a flipped ReLU' if loose else 'no flip behind it', flips)
         if e_hip > worst.get(loose, (0,))[0]:
             worst[loose] = (e_hip, e_f32, name)
-    print(f'[grad parity] worst strict: {worst.get(False)}  worst behind a flip: {worst.get(True)}')
+    _report(f'[grad parity] R{depth} S={S} B={B} {conv_arith}: worst (relL2 hip, relL2 fp32 CPU, name) with no flip behind: '
+            f'{worst.get(False)}; behind a flip: {worst.get(True)}')
     # BN running statistics
     rb, ob = dict(ref.named_buffers()), dict(mod.named_buffers())
     for name, b in rb.items():
