@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _lib = None
 
@@ -52,6 +52,13 @@ SIGNATURES = {
     'bdv_conv_dgrad_stat_rows': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_dgrad': (c_int, [P, P, P, P, P, POINTER(ConvGeom), POINTER(BnStatFuse), P, c_size_t, P]),
     'bdv_conv_dgrad_x3': (c_int, [P, P, P, P, P, P, POINTER(ConvGeom), POINTER(BnStatFuse), P, c_size_t, P]),
+    'bdv_conv_weight_planes_bytes': (c_size_t, [POINTER(ConvGeom)]),
+    'bdv_conv_split_weights': (c_int, [P, POINTER(ConvGeom), P, P, P]),
+    'bdv_conv_debug_force_tile': (c_int, [c_int]),
+    'bdv_conv_fprop_pl_stat_rows': (c_int, [POINTER(ConvGeom)]),
+    'bdv_conv_dgrad_pl_stat_rows': (c_int, [POINTER(ConvGeom)]),
+    'bdv_conv_fprop_pl': (c_int, [P, P, P, P, POINTER(ConvGeom), P, POINTER(ConvAffine), P, c_size_t, P]),
+    'bdv_conv_dgrad_pl': (c_int, [P, P, P, P, P, P, POINTER(ConvGeom), POINTER(BnStatFuse), P, c_size_t, P]),
     'bdv_conv_wgrad': (c_int, [P, P, P, c_float, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_conv_wgrad_splits': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_wgrad_partial': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, P]),

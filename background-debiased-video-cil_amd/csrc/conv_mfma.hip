@@ -182,15 +182,15 @@ __device__ __forceinline__ WorkItem get_work(int b, const Work& wk, int nk) {
   return it;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int NT = 256>
 __device__ __forceinline__ void store_partial(float* __restrict__ slab, int pslot, const f32x16 (&acc)[TM][TN], int tid) {
-  float* base = slab + (size_t)pslot * (TM * TN * 16) * 256 + tid;
+  float* base = slab + (size_t)pslot * (TM * TN * 16) * NT + tid;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) base[(size_t)((i * TN + j) * 16 + e) * 256] = acc[i][j][e];
+      for (int e = 0; e < 16; ++e) base[(size_t)((i * TN + j) * 16 + e) * NT] = acc[i][j][e];
 }
 
 template <int TM, int TN>
@@ -239,10 +239,10 @@ struct StatAcc {
 };
 
 // tile reduction of the per-thread sums: thread = (row group tid / V, column vector tid % V), V = BN / 4
-template <int BN>
+template <int BN, int NT = 256>
 __device__ __forceinline__ void stat_flush(const StatAcc& a, const BnStat& st, float* __restrict__ smem, int Cin, int mt, int nt,
                                            int tid) {
-  constexpr int V = BN / 4, G = 256 / V;
+  constexpr int V = BN / 4, G = NT / V;
   __syncthreads();  // every thread is done reading the staged tile
   const int grp = tid / V, c4 = tid - grp * V;
   *reinterpret_cast<float4*>(smem + grp * BN + 4 * c4) = a.s1;
@@ -268,8 +268,9 @@ template <int BM, int BN, int WM, int WN, class F>
 __device__ __forceinline__ void staged_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ smem, int tid,
                                                 F&& emit) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NT = 64 * WM * WN;
   constexpr int V = BN / 4;                     // float4 per row
-  constexpr int PER = WM * 32 * V / 256;        // float4 per thread per pass
+  constexpr int PER = WM * 32 * V / NT;         // float4 per thread per pass
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn0 = (wave % WN) * 32;
 #pragma unroll
@@ -282,7 +283,7 @@ __device__ __forceinline__ void staged_epilogue(const f32x16 (&acc)[BM / WM / 32
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-      const int idx = tid + 256 * q;
+      const int idx = tid + NT * q;
       const int lr = idx / V, c4 = idx - lr * V;
       const float4 v = *reinterpret_cast<const float4*>(smem + lr * BN + 4 * c4);
       emit(32 * WM * i + lr, 4 * c4, v);  // staged row lr = 32 * wave_m + r  ->  tile row 32*WM*i + lr
@@ -304,8 +305,9 @@ __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32]
                                                const uint32_t* __restrict__ add_mask, const Geom& g, int mt, int nt, int Mrows,
                                                const BnStat& stat, RowMap&& rowmap) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NT = 64 * WM * WN;
   constexpr int V = BN / 4;
-  constexpr int PER = WM * 32 * V / 256;
+  constexpr int PER = WM * 32 * V / NT;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn0 = (wave % WN) * 32;
   const int HW = g.H * g.W;
@@ -342,7 +344,7 @@ __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32]
       int off[HB];
 #pragma unroll
       for (int u = 0; u < HB; ++u) {
-        const int lr = (tid + 256 * (q0 + u)) / V;
+        const int lr = (tid + NT * (q0 + u)) / V;
         const int mrow = mt * BM + 32 * WM * i + lr;
         const bool ok = mrow < Mrows;
         const int row = rowmap(ok ? mrow : 0);
@@ -389,7 +391,7 @@ __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32]
       }
     }
   }
-  if (do_stat) stat_flush<BN>(sa, stat, smem, g.Cin, mt, nt, tid);
+  if (do_stat) stat_flush<BN, NT>(sa, stat, smem, g.Cin, mt, nt, tid);
 }
 
 // BatchNorm batch statistics fused into the fprop epilogue: per tile, the column sums of y and y^2 over the
@@ -444,8 +446,9 @@ __device__ __forceinline__ void fprop_affine_epilogue(const f32x16 (&acc)[BM / W
                                                       float* __restrict__ y, const Geom& g, const FpropEpi& epi, int mt, int nt,
                                                       int tid) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NT = 64 * WM * WN;
   constexpr int V = BN / 4;
-  constexpr int PER = WM * 32 * V / 256;
+  constexpr int PER = WM * 32 * V / NT;
   constexpr int HB = PER < 4 ? PER : 4;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn0 = (wave % WN) * 32;
@@ -470,7 +473,7 @@ __device__ __forceinline__ void fprop_affine_epilogue(const f32x16 (&acc)[BM / W
       int off[HB];
 #pragma unroll
       for (int u = 0; u < HB; ++u) {
-        const int lr = (tid + 256 * (q0 + u)) / V;
+        const int lr = (tid + NT * (q0 + u)) / V;
         const int row = mt * BM + 32 * WM * i + lr;
         off[u] = row < g.M ? (row * g.Cout + col) * 4 : kOOB;
         v[u] = *reinterpret_cast<const float4*>(smem + lr * BN + 4 * (tid % V));
@@ -926,10 +929,11 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __re
 // element store (and BN column statistics) as the main kernel.  grid = rem_tiles, 256 threads mapped like the
 // main kernel.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_fprop_fixup_kernel(const float* __restrict__ slab, float* __restrict__ y, Geom g,
+__global__ __launch_bounds__(64 * WM * WN) void conv_fprop_fixup_kernel(const float* __restrict__ slab, float* __restrict__ y, Geom g,
                                                                 int NT, Work wk, FpropEpi epi) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NACC = TM * TN * 16;
+  constexpr int NTHR = 64 * WM * WN;
   __shared__ __attribute__((aligned(16))) float smem[WM * 32 * BN];
   const int rt = blockIdx.x, tile = wk.dp_tiles + rt;
   const int mt = tile / NT, nt = tile - mt * NT;
@@ -938,13 +942,13 @@ __global__ __launch_bounds__(256) void conv_fprop_fixup_kernel(const float* __re
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   for (int sl = 0; sl < wk.split; ++sl) {
-    const float* src = slab + (size_t)(rt * wk.split + sl) * NACC * 256 + tid;
+    const float* src = slab + (size_t)(rt * wk.split + sl) * NACC * NTHR + tid;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] += src[(size_t)((i * TN + j) * 16 + e) * 256];
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += src[(size_t)((i * TN + j) * 16 + e) * NTHR];
   }
   fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
 }
@@ -1228,12 +1232,13 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_x3_kernel(const float* __re
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_dgrad_fixup_kernel(const float* __restrict__ slab, float* __restrict__ dx,
+__global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_fixup_kernel(const float* __restrict__ slab, float* __restrict__ dx,
                                                                 const float* __restrict__ add_src,
                                                                 const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk,
                                                                 BnStat stat) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NACC = TM * TN * 16;
+  constexpr int NTHR = 64 * WM * WN;
   __shared__ __attribute__((aligned(16))) float smem[WM * 32 * BN];
   const int rt = blockIdx.x, tile = wk.dp_tiles + rt;
   const int mt = tile / NT, nt = tile - mt * NT;
@@ -1241,13 +1246,13 @@ __global__ __launch_bounds__(256) void conv_dgrad_fixup_kernel(const float* __re
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   for (int sl = 0; sl < wk.split; ++sl) {
-    const float* src = slab + (size_t)(rt * wk.split + sl) * NACC * 256 + tid;
+    const float* src = slab + (size_t)(rt * wk.split + sl) * NACC * NTHR + tid;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] += src[(size_t)((i * TN + j) * 16 + e) * 256];
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += src[(size_t)((i * TN + j) * 16 + e) * NTHR];
   }
   dgrad_epilogue<BM, BN, WM, WN>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, g.M, stat, [](int mrow) { return mrow; });
 }
@@ -1666,6 +1671,416 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(ReduceBatch r
   wgrad_reduce_block(rb.slab[k], rb.dw[k], beta, rb.splits[k], rb.numel4[k], blockIdx.x - rb.first_block[k]);
 }
 
+// =========================================================================================
+// Round-2 kernels for the bf16-piece arithmetic ("P" family): 8 waves per workgroup, one workgroup per CU, the weights
+// pre-split once per step into bf16 planes (bdv_conv_split_weights), two LDS stages and one barrier per K-step.
+//
+// What changed against conv_fprop_x3_kernel / conv_dgrad_x3_kernel, and why (tools/ubench/gemm_x3p.hip, profiles/r02_*):
+// those kernels sit at ~37 % of the bf16 MFMA time because every K-step pays, per 48 MFMAs of a wave, ~180 VALU instructions
+// for splitting BOTH operand tiles into pieces plus 24 LDS stores, and the issue slots of a SIMD are full before its matrix
+// pipe is.  Here
+//   * the weight operand arrives as ready-made planes [piece][K-step][row][32] (a K-step's tile is one contiguous block):
+//     16-byte loads, ds_write_b128, no VALU;
+//   * the activation tile is split once per 256 (or 128) output columns instead of once per 128: VALU per MFMA halves again;
+//   * LDS rows are 64 bytes (32 bf16), unpadded, with the 16-byte chunk index XOR-ed by (row >> 2) & 3: fragment reads
+//     (ds_read_b128) and both kinds of stores are conflict-free, and two stages of a 128x256 tile fit in 144 KB;
+//   * with two stages the registers of step k+1 are split and stored while other waves still read stage k: one barrier per
+//     K-step, and the compiler interleaves the split with the MFMAs.
+// Loader (halo / clip-end / ragged rows via out-of-range buffer offsets), work planner, K-split fix-ups and all epilogues are
+// the ones of the kernels above.
+// =========================================================================================
+
+// byte offset of 16-byte chunk c (0..3) of row `row` in a plane image of 64-byte rows
+__device__ __forceinline__ int pl_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+// fp32 x 4 (row `row`, floats 4 kg .. 4 kg + 3 of the 32-deep step) -> hi / mid / lo planes of the stage image
+__device__ __forceinline__ void pl_split_store(unsigned char* __restrict__ base, int plane_bytes, int row, int kg, const float4 v) {
+  const f32x4_t a = {v.x, v.y, v.z, v.w};
+  const bf16x4_t hi = __builtin_convertvector(a, bf16x4_t);
+  const f32x4_t r1 = a - __builtin_convertvector(hi, f32x4_t);
+  const bf16x4_t mid = __builtin_convertvector(r1, bf16x4_t);
+  const f32x4_t r2 = r1 - __builtin_convertvector(mid, f32x4_t);
+  const bf16x4_t lo = __builtin_convertvector(r2, bf16x4_t);
+  unsigned char* q = base + pl_off(row, kg >> 1) + 8 * (kg & 1);
+  *reinterpret_cast<bf16x4_t*>(q) = hi;
+  *reinterpret_cast<bf16x4_t*>(q + plane_bytes) = mid;
+  *reinterpret_cast<bf16x4_t*>(q + 2 * plane_bytes) = lo;
+}
+
+// 32-deep K-step on one stage: wave (wm, wn) owns rows 32 WM i + 32 wm + r and columns 32 WN j + 32 wn + c (interleaved
+// tiling, as the epilogues expect)
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void mma_stage_pl(const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs,
+                                             f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn, int lane) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int PA = BM * 64, PB = BN * 64;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < BK / 16; ++s) {
+    bf16x8_t a[3][TM], b[3][TN];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[p][i] = *reinterpret_cast<const bf16x8_t*>(As + p * PA + pl_off(32 * WM * i + 32 * wm + r, 2 * s + h));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[p][j] = *reinterpret_cast<const bf16x8_t*>(Bs + p * PB + pl_off(32 * WN * j + 32 * wn + r, 2 * s + h));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {  // smallest terms first
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+      }
+  }
+}
+
+// ---- weights -> bf16 planes ------------------------------------------------------------------
+// F (fprop):  [piece][K-step = chunk * R*S + tap][co][32 ci of the chunk]      (chunk = ci / 32; tap-fastest, the K order of fprop)
+// D (dgrad):  [piece][tap][co chunk][ci][32 co of the chunk]                   (the contraction index co contiguous per ci row)
+// One block = one (32 co x 32 ci) tile of one tap; D is written through an LDS transpose so both stores are 64-byte rows.
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ F,
+                                                             unsigned short* __restrict__ D, int Cout, int RS, int Cin) {
+  __shared__ unsigned short tile[3][32][34];
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, tap = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t plane = (size_t)Cout * RS * Cin;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int co_l = ty + 8 * p;
+    const float a = w[((size_t)(co0 + co_l) * RS + tap) * Cin + ci0 + tx];
+    const __bf16 hi = (__bf16)a;
+    const float r1 = a - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    const __bf16 lo = (__bf16)(r1 - (float)mid);
+    const unsigned short h16 = __builtin_bit_cast(unsigned short, hi), m16 = __builtin_bit_cast(unsigned short, mid),
+                         l16 = __builtin_bit_cast(unsigned short, lo);
+    if (F != nullptr) {
+      const size_t o = (((size_t)(ci0 >> 5) * RS + tap) * Cout + co0 + co_l) * 32 + tx;
+      F[o] = h16;
+      F[plane + o] = m16;
+      F[2 * plane + o] = l16;
+    }
+    tile[0][co_l][tx] = h16;
+    tile[1][co_l][tx] = m16;
+    tile[2][co_l][tx] = l16;
+  }
+  if (D == nullptr) return;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ci_l = ty + 8 * p;  // tx = co within the chunk
+    const size_t o = (((size_t)tap * (Cout >> 5) + (co0 >> 5)) * Cin + ci0 + ci_l) * 32 + tx;
+    D[o] = tile[0][tx][ci_l];
+    D[plane + o] = tile[1][tx][ci_l];
+    D[2 * plane + o] = tile[2][tx][ci_l];
+  }
+}
+
+// ---- fprop ------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int NBUF>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_kernel(const float* __restrict__ x,
+                                                                                      const unsigned short* __restrict__ wp,
+                                                                                      float* __restrict__ y, Geom g, int NT, Work wk,
+                                                                                      float* __restrict__ slab, FpropEpi epi) {
+  constexpr int NTHR = 64 * WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AP = BM * 8 / NTHR;    // float4 loads of the activation tile per thread and K-step
+  constexpr int BPP = BN * 4 / NTHR;   // 16-byte loads per weight plane per thread and K-step
+  constexpr int PA = BM * 64, PB = BN * 64, STAGE = 3 * (PA + PB);
+  static_assert(AP >= 1 && BPP >= 1 && NBUF * STAGE >= WM * 32 * BN * 4, "tile / epilogue staging do not fit");
+  __shared__ __attribute__((aligned(16))) unsigned char smem_b[NBUF * STAGE];
+  float* const smem = reinterpret_cast<float*>(smem_b);
+
+  const int nk = g.Ktot / BK;
+  const WorkItem it = get_work(blockIdx.x, wk, nk);
+  const int mt = it.tile / NT, nt = it.tile - mt * NT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int arow = tid >> 3, kg = tid & 7;
+  const int brow = tid >> 2, bc = tid & 3;
+  const int HoWo = g.Ho * g.Wo;
+  const int frame_bytes = g.H * g.W * g.Cin * 4;
+  const int plane_bytes = g.Cout * g.Ktot * 2;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * frame_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 3 * plane_bytes, 0x00020000);
+
+  int a_base[AP], a_t[AP], a_hi0[AP], a_wi0[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int m = mt * BM + arow + (NTHR / 8) * p;
+    const bool ok = m < g.M;
+    int n, rem, ho, wo;
+    fast_divmod(ok ? m : 0, HoWo, g.rcp_HoWo, n, rem);
+    fast_divmod(rem, g.Wo, g.rcp_Wo, ho, wo);
+    a_t[p] = n % g.T;
+    a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);  // rows past M fail every bounds test
+    a_wi0[p] = wo * g.stride - g.pad;
+    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad) * g.Cin * 4 + 16 * kg;
+  }
+  int b_base[BPP];
+#pragma unroll
+  for (int q = 0; q < BPP; ++q) b_base[q] = (nt * BN + brow + (NTHR / 4) * q) * 64 + 16 * bc;
+
+  // K index state (uniform): K-step kt = chunk * R*S + r * S + s; the weight planes are stored in this order
+  const int RS = g.R * g.S;
+  int chunk = it.kb / RS, r, s, kt_w = it.kb;
+  {
+    const int tap = it.kb - chunk * RS;
+    r = tap / g.S;
+    s = tap - r * g.S;
+  }
+
+  float4 ra[AP];
+  u32x4 rb[3 * BPP];
+  auto load = [&]() {
+    const int cls = shift_class(chunk * BK + 4 * kg, g.fold);
+    const int koff_a = ((r * g.W + s) * g.Cin + chunk * BK) * 4;
+    const int koff_b = kt_w * g.Cout * 64;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const bool v = (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W &&
+                     (unsigned)(a_t[p] + cls) < (unsigned)g.T;
+      ra[p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB), 0);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int q = 0; q < BPP; ++q) rb[pl * BPP + q] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_base[q] + pl * plane_bytes, koff_b, 0);
+    kt_w += 1;
+    s += 1;
+    const int ws_ = (s == g.S) ? 1 : 0;
+    s = ws_ ? 0 : s;
+    r += ws_;
+    const int wr_ = (r == g.R) ? 1 : 0;
+    r = wr_ ? 0 : r;
+    chunk += wr_;
+  };
+  auto store = [&](int stage) {
+    unsigned char* const As = smem_b + stage * STAGE;
+    unsigned char* const Bs = As + 3 * PA;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) pl_split_store(As, PA, arow + (NTHR / 8) * p, kg, ra[p]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + pl * PB + pl_off(brow + (NTHR / 4) * q, bc)) = rb[pl * BPP + q];
+  };
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+
+  if constexpr (NBUF == 2) {
+    int kt = it.kb;
+    load();
+    store(0);
+    if (kt + 1 < it.ke) load();
+    __syncthreads();
+    while (true) {
+      mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, wm, wn, lane);
+      if (kt + 1 < it.ke) store(1);
+      if (kt + 2 < it.ke) load();
+      __syncthreads();
+      if (++kt >= it.ke) break;
+      mma_stage_pl<BM, BN, WM, WN>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, wm, wn, lane);
+      if (kt + 1 < it.ke) store(0);
+      if (kt + 2 < it.ke) load();
+      __syncthreads();
+      if (++kt >= it.ke) break;
+    }
+  } else {
+    load();
+    for (int kt = it.kb; kt < it.ke; ++kt) {
+      __syncthreads();
+      store(0);
+      __syncthreads();
+      if (kt + 1 < it.ke) load();
+      mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, wm, wn, lane);
+    }
+  }
+
+  if (it.pslot >= 0) {
+    store_partial<TM, TN, NTHR>(slab, it.pslot, acc, tid);
+    return;
+  }
+  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
+}
+
+// ---- dgrad ------------------------------------------------------------------------------------
+// dp = the D planes of bdv_conv_split_weights: B rows = input channels ci, contraction over (tap, co) with co contiguous.
+template <int BM, int BN, int WM, int WN, int NBUF>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_kernel(const float* __restrict__ dy,
+                                                                                      const unsigned short* __restrict__ dp,
+                                                                                      float* __restrict__ dx,
+                                                                                      const float* __restrict__ add_src,
+                                                                                      const uint32_t* __restrict__ add_mask, Geom g,
+                                                                                      int NT, Work wk, float* __restrict__ slab,
+                                                                                      BnStat stat) {
+  constexpr int NTHR = 64 * WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AP = BM * 8 / NTHR;
+  constexpr int BPP = BN * 4 / NTHR;
+  constexpr int PA = BM * 64, PB = BN * 64, STAGE = 3 * (PA + PB);
+  static_assert(AP >= 1 && BPP >= 1 && NBUF * STAGE >= WM * 32 * BN * 4, "tile / epilogue staging do not fit");
+  __shared__ __attribute__((aligned(16))) unsigned char smem_b[NBUF * STAGE];
+  float* const smem = reinterpret_cast<float*>(smem_b);
+
+  // parity class of the input pixel (stride 1: a single class)
+  const int st = g.stride;
+  const int ph = blockIdx.y / st, pw = blockIdx.y - ph * st;
+  const int Hc = (g.H - ph + st - 1) / st, Wc = (g.W - pw + st - 1) / st;
+  const int Mc = g.N * Hc * Wc;
+  const int MT = (Mc + BM - 1) / BM;
+  const int r0 = (ph + g.pad) % st, s0 = (pw + g.pad) % st;
+  const int nr = r0 < g.R ? (g.R - r0 + st - 1) / st : 0;
+  const int ns = s0 < g.S ? (g.S - s0 + st - 1) / st : 0;
+  const int bh = (ph + g.pad - r0) / st, bw = (pw + g.pad - s0) / st;
+  const int ntap = nr * ns;
+  const int nk = ntap * g.Cout / BK;  // 0 for a class no filter tap reaches (e.g. 1x1 stride 2, odd pixels)
+
+  int mt, nt;
+  WorkItem it;
+  if (st == 1) {
+    it = get_work(blockIdx.x, wk, nk);
+    mt = it.tile / NT;
+    nt = it.tile - mt * NT;
+  } else {  // parity classes have different sizes: padded grid, no K split
+    const int id = blockIdx.x;
+    const int xcd = id & 7, jj = id >> 3;
+    mt = (jj / NT) * 8 + xcd;
+    nt = jj % NT;
+    if (mt >= MT) return;
+    it.tile = 0;
+    it.kb = 0;
+    it.ke = nk;
+    it.pslot = -1;
+  }
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int arow = tid >> 3, kg = tid & 7;
+  const int brow = tid >> 2, bc = tid & 3;
+  const int HcWc = Hc * Wc;
+  const int RS = g.R * g.S;
+  const int plane_bytes = g.Cout * RS * g.Cin * 2;
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.N * g.Ho * g.Wo * g.Cout * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)dp, 0, 3 * plane_bytes, 0x00020000);
+
+  int a_base[AP], a_h[AP], a_w[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int m = mt * BM + arow + (NTHR / 8) * p;
+    const bool ok = m < Mc;
+    const int mm = ok ? m : 0;
+    const int n = mm / HcWc;
+    const int rem = mm - n * HcWc;
+    const int hc = rem / Wc, wc = rem - hc * Wc;
+    a_h[p] = ok ? hc + bh : -(1 << 20);
+    a_w[p] = wc + bw;
+    a_base[p] = ((n * g.Ho + hc + bh) * g.Wo + wc + bw) * g.Cout * 4 + 16 * kg;
+  }
+  int b_base[BPP];
+#pragma unroll
+  for (int q = 0; q < BPP; ++q) b_base[q] = (nt * BN + brow + (NTHR / 4) * q) * 64 + 16 * bc;
+
+  // K index state (uniform): kt = chunk * ntap + ir * ns + is  (tap-fastest)
+  int chunk = ntap > 0 ? it.kb / ntap : 0, ir, is;
+  {
+    const int ct = ntap > 0 ? it.kb - chunk * ntap : 0;
+    ir = ns > 0 ? ct / ns : 0;
+    is = ct - ir * ns;
+  }
+  const int nchunk = g.Cout / BK;
+
+  float4 ra[AP];
+  u32x4 rb[3 * BPP];
+  auto load = [&]() {
+    const int tap = (r0 + ir * st) * g.S + (s0 + is * st);
+    const int koff_a = (chunk * BK - (ir * g.Wo + is) * g.Cout) * 4;
+    const int koff_b = (tap * nchunk + chunk) * g.Cin * 64;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const bool v = (unsigned)(a_h[p] - ir) < (unsigned)g.Ho && (unsigned)(a_w[p] - is) < (unsigned)g.Wo;
+      ra[p] = buf_load16(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB), 0);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int q = 0; q < BPP; ++q) rb[pl * BPP + q] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_base[q] + pl * plane_bytes, koff_b, 0);
+    is += 1;
+    const int w1 = (is == ns) ? 1 : 0;
+    is = w1 ? 0 : is;
+    ir += w1;
+    const int w2 = (ir == nr) ? 1 : 0;
+    ir = w2 ? 0 : ir;
+    chunk += w2;
+  };
+  auto store = [&](int stage) {
+    unsigned char* const As = smem_b + stage * STAGE;
+    unsigned char* const Bs = As + 3 * PA;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) pl_split_store(As, PA, arow + (NTHR / 8) * p, kg, ra[p]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + pl * PB + pl_off(brow + (NTHR / 4) * q, bc)) = rb[pl * BPP + q];
+  };
+
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+
+  if (it.ke > it.kb) {
+    if constexpr (NBUF == 2) {
+      int kt = it.kb;
+      load();
+      store(0);
+      if (kt + 1 < it.ke) load();
+      __syncthreads();
+      while (true) {
+        mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, wm, wn, lane);
+        if (kt + 1 < it.ke) store(1);
+        if (kt + 2 < it.ke) load();
+        __syncthreads();
+        if (++kt >= it.ke) break;
+        mma_stage_pl<BM, BN, WM, WN>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, wm, wn, lane);
+        if (kt + 1 < it.ke) store(0);
+        if (kt + 2 < it.ke) load();
+        __syncthreads();
+        if (++kt >= it.ke) break;
+      }
+    } else {
+      load();
+      for (int kt = it.kb; kt < it.ke; ++kt) {
+        __syncthreads();
+        store(0);
+        __syncthreads();
+        if (kt + 1 < it.ke) load();
+        mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, wm, wn, lane);
+      }
+    }
+  }
+  if (it.pslot >= 0) {
+    store_partial<TM, TN, NTHR>(slab, it.pslot, acc, tid);
+    return;
+  }
+  dgrad_epilogue<BM, BN, WM, WN>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
+    if (st == 1) return mrow;
+    const int n = mrow / HcWc;
+    const int rem = mrow - n * HcWc;
+    const int hc = rem / Wc;
+    return (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
+  });
+}
+
 // ---- host side --------------------------------------------------------------------------------
 
 int check_geom(const bdv_conv_geom* g, const char* who) {
@@ -1752,6 +2167,7 @@ Work plan_work(int tiles, int nk, double iter_us, size_t seg_bytes, size_t ws_by
   return wk;
 }
 
+
 constexpr size_t kMaxSplitWorkspace = 160ull << 20;
 
 struct FdPlan {
@@ -1801,6 +2217,99 @@ FdPlan plan_dgrad(const Geom& g, size_t ws_bytes, bool x3 = false) {
   }
   return p;
 }
+
+// ---- planner of the "P" kernels (8 waves, ONE workgroup per CU: a round is 256 blocks) ----------------------------------
+// Tile configurations: 0 = 128 x 256 (two LDS stages), 1 = 256 x 128 (two stages), 2 = 256 x 256 (one stage).
+struct PlCfg {
+  int BM, BN, nbuf;
+  double iter_us;  // one 32-deep K-step of a block, measured per-CU rate (tools/ubench/gemm_x3p.hip: ~200 / ~230 TFLOP/s chip-wide)
+};
+constexpr PlCfg kPlCfg[3] = {{128, 256, 2, 2.7}, {256, 128, 2, 2.7}, {256, 256, 1, 4.7}};
+
+struct PlPlan {
+  int cfg;  // -1: shape not covered by the P kernels
+  int MT, NT, nk;
+  size_t seg_bytes;
+  Work wk;
+  double est_us;
+};
+
+// DP whole rounds of 256 blocks, the remainder tiles K-split `s` ways (fix-up kernel): cost in us incl. the fix-up's slab traffic
+Work plan_work_pl(int tiles, int nk, double iter_us, size_t seg_bytes, size_t ws_bytes, double* est_us) {
+  const int W = 256;
+  Work wk;
+  const int q = tiles / W, r = tiles - q * W;
+  wk.dp_tiles = tiles;
+  wk.rem_tiles = 0;
+  wk.split = 1;
+  double best = (double)(q + (r > 0 ? 1 : 0)) * nk * iter_us;
+  if (r > 0 && nk >= 4) {
+    for (int sp = 2; sp <= 16 && nk / sp >= 2; ++sp) {
+      const size_t need = (size_t)r * sp * seg_bytes;
+      if (need > ws_bytes) break;
+      const int rounds = (r * sp + W - 1) / W;
+      const int per = (nk + sp - 1) / sp;
+      const double cost = ((double)q * nk + (double)rounds * per) * iter_us + 8.0 + 2.0 * (double)need / 4.0e6;
+      if (cost < best * 0.97) {
+        best = cost;
+        wk.dp_tiles = q * W;
+        wk.rem_tiles = r;
+        wk.split = sp;
+      }
+    }
+  }
+  *est_us = best;
+  return wk;
+}
+
+// Tile override for tests and A/B runs: BDVCIL_PL_TILE (read once) or bdv_conv_debug_force_tile(); -1 = choose by the cost model.
+int g_pl_tile_forced = -2;  // -2: not initialised
+int pl_tile_override() {
+  if (g_pl_tile_forced == -2) g_pl_tile_forced = getenv("BDVCIL_PL_TILE") ? atoi(getenv("BDVCIL_PL_TILE")) : -1;
+  return g_pl_tile_forced;
+}
+
+// M = GEMM rows, ncols = GEMM columns (Cout for fprop, Cin for dgrad), nk = 32-deep K-steps; ksplit_ok: stride-1 launches only
+PlPlan plan_pl(int M, int ncols, int nk, size_t ws_bytes, bool ksplit_ok) {
+  PlPlan best;
+  best.cfg = -1;
+  best.est_us = 1e30;
+  const int forced = pl_tile_override();
+  for (int c = 0; c < 3; ++c) {
+    const PlCfg& k = kPlCfg[c];
+    if (ncols % k.BN != 0) continue;
+    if (ncols % 256 == 0 && c == 1 && forced != 1) continue;  // 256-wide outputs: the activation tile is then split once per 256 columns
+    if (forced >= 0 && forced != c && ncols % kPlCfg[forced].BN == 0) continue;
+    PlPlan p;
+    p.cfg = c;
+    p.MT = (M + k.BM - 1) / k.BM;
+    p.NT = ncols / k.BN;
+    p.nk = nk;
+    p.seg_bytes = (size_t)k.BM * k.BN * sizeof(float);
+    if (ksplit_ok) {
+      p.wk = plan_work_pl(p.MT * p.NT, nk, k.iter_us, p.seg_bytes, ws_bytes, &p.est_us);
+    } else {
+      p.wk.dp_tiles = p.MT * p.NT;
+      p.wk.rem_tiles = 0;
+      p.wk.split = 1;
+      p.est_us = (double)((p.MT * p.NT + 255) / 256) * nk * k.iter_us;
+    }
+    if (p.est_us < best.est_us) best = p;
+  }
+  return best;
+}
+
+// The tile configuration (hence the row count of the fused-statistics partials) must not depend on the caller's workspace:
+// it is chosen for the full split budget, and only the K-split is re-planned for the workspace actually passed.
+PlPlan plan_pl_ws(int M, int ncols, int nk, size_t ws_bytes, bool ksplit_ok) {
+  PlPlan p = plan_pl(M, ncols, nk, kMaxSplitWorkspace, ksplit_ok);
+  if (p.cfg >= 0 && ksplit_ok && ws_bytes < kMaxSplitWorkspace)
+    p.wk = plan_work_pl(p.MT * p.NT, nk, kPlCfg[p.cfg].iter_us, p.seg_bytes, ws_bytes, &p.est_us);
+  return p;
+}
+
+bool pl_fprop_ok(const bdv_conv_geom* g) { return g->Cin % BK == 0 && g->Cout % 128 == 0; }
+bool pl_dgrad_ok(const bdv_conv_geom* g) { return g->Cout % BK == 0 && g->Cin % 128 == 0; }
 
 struct WgradPlan {
   bool small;  // 64x64 tiles
@@ -1865,7 +2374,17 @@ extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
     g.Ktot = g.R * g.S * g.Cout;
     p = plan_dgrad(g, kMaxSplitWorkspace);
   }
-  const size_t need = p.wk.split > 1 ? (size_t)p.wk.rem_tiles * p.wk.split * p.seg_bytes : 0;
+  size_t need = p.wk.split > 1 ? (size_t)p.wk.rem_tiles * p.wk.split * p.seg_bytes : 0;
+  // the P kernels (bdv_conv_fprop_pl / bdv_conv_dgrad_pl) plan their own K-split
+  if (kind == 0 && pl_fprop_ok(gg)) {
+    const PlPlan q = plan_pl(g.M, g.Cout, g.Ktot / BK, kMaxSplitWorkspace, true);
+    const size_t n2 = q.wk.split > 1 ? (size_t)q.wk.rem_tiles * q.wk.split * q.seg_bytes : 0;
+    need = n2 > need ? n2 : need;
+  } else if (kind == 1 && pl_dgrad_ok(gg) && gg->stride == 1) {
+    const PlPlan q = plan_pl(g.M, g.Cin, g.Ktot / BK, kMaxSplitWorkspace, true);
+    const size_t n2 = q.wk.split > 1 ? (size_t)q.wk.rem_tiles * q.wk.split * q.seg_bytes : 0;
+    need = n2 > need ? n2 : need;
+  }
   return need > 16 ? need : 16;
 }
 
@@ -2014,6 +2533,157 @@ extern "C" int bdv_conv_dgrad_x3(const float* dy, const float* w, const float* w
                                  void* workspace, size_t workspace_bytes, void* stream) {
   BDV_REQUIRE(w_t != nullptr, "bdv_conv_dgrad_x3: w_t is null");
   return conv_dgrad_impl(dy, w, w_t, dx, add_src, add_mask_src, gg, bn_stat, workspace, workspace_bytes, stream);
+}
+
+// ---- weights as bf16 planes + the P kernels --------------------------------------------------------------------------
+extern "C" size_t bdv_conv_weight_planes_bytes(const bdv_conv_geom* gg) {
+  if (check_geom(gg, "bdv_conv_weight_planes_bytes")) return 0;
+  return (size_t)3 * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(unsigned short);
+}
+
+extern "C" int bdv_conv_debug_force_tile(int cfg) {
+  BDV_REQUIRE(cfg >= -1 && cfg <= 2, "bdv_conv_debug_force_tile: cfg %d (-1 automatic, 0 = 128x256, 1 = 256x128, 2 = 256x256)", cfg);
+  g_pl_tile_forced = cfg;
+  return BDV_OK;
+}
+
+extern "C" int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* gg) {
+  if (check_geom(gg, "bdv_conv_fprop_pl_stat_rows")) return 0;
+  if (!pl_fprop_ok(gg)) return bdv_conv_fprop_stat_rows(gg);
+  const PlPlan p = plan_pl(gg->N * gg->Ho * gg->Wo, gg->Cout, gg->R * gg->S * gg->Cin / BK, kMaxSplitWorkspace, true);
+  return p.cfg >= 0 ? p.MT : 0;
+}
+
+extern "C" int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* gg) {
+  if (check_geom(gg, "bdv_conv_dgrad_pl_stat_rows")) return 0;
+  if (!pl_dgrad_ok(gg) || gg->stride != 1) return bdv_conv_dgrad_stat_rows(gg);
+  const PlPlan p = plan_pl(gg->N * gg->H * gg->W, gg->Cin, gg->R * gg->S * gg->Cout / BK, kMaxSplitWorkspace, true);
+  return p.cfg >= 0 ? p.MT : 0;
+}
+
+extern "C" int bdv_conv_split_weights(const float* w, const bdv_conv_geom* gg, void* planes_fprop, void* planes_dgrad, void* stream) {
+  if (int e = check_geom(gg, "bdv_conv_split_weights")) return e;
+  BDV_REQUIRE(w && (planes_fprop || planes_dgrad), "bdv_conv_split_weights: null pointer");
+  BDV_REQUIRE(gg->Cin % 32 == 0 && gg->Cout % 32 == 0, "bdv_conv_split_weights: Cin=%d and Cout=%d must be multiples of 32", gg->Cin, gg->Cout);
+  BDV_REQUIRE(bdv_aligned16(w) && bdv_aligned16(planes_fprop) && bdv_aligned16(planes_dgrad), "bdv_conv_split_weights: alignment");
+  const dim3 grid(gg->Cin / 32, gg->Cout / 32, gg->R * gg->S);
+  hipLaunchKernelGGL(split_weights_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)planes_fprop,
+                     (unsigned short*)planes_dgrad, gg->Cout, gg->R * gg->S, gg->Cin);
+  BDV_LAUNCH_CHECK("bdv_conv_split_weights");
+  return BDV_OK;
+}
+
+extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* planes_fprop, float* y, const bdv_conv_geom* gg,
+                                 float* bn_partial, const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  if (int e = check_geom(gg, "bdv_conv_fprop_pl")) return e;
+  if (planes_fprop == nullptr || !pl_fprop_ok(gg))  // shapes outside the P kernels: the fp32-operand entry point
+    return conv_fprop_impl(x, w, y, gg, bn_partial, affine, workspace, workspace_bytes, stream, true);
+  BDV_REQUIRE(x && y, "bdv_conv_fprop_pl: null pointer");
+  FpropEpi epi = {bn_partial, 0, nullptr, nullptr, nullptr, 0};
+  if (affine != nullptr) {
+    BDV_REQUIRE(bn_partial == nullptr, "bdv_conv_fprop_pl: batch statistics and the folded eval-mode BatchNorm exclude each other");
+    BDV_REQUIRE(affine->scale && affine->shift, "bdv_conv_fprop_pl: null pointer in bdv_conv_affine");
+    BDV_REQUIRE(bdv_aligned16(affine->scale) && bdv_aligned16(affine->shift) && bdv_aligned16(affine->residual),
+                "bdv_conv_fprop_pl: bdv_conv_affine pointers must be 16-byte aligned");
+    epi.scale = affine->scale;
+    epi.shift = affine->shift;
+    epi.res = affine->residual;
+    epi.relu = affine->relu;
+  }
+  BDV_REQUIRE(bdv_aligned16(x) && bdv_aligned16(planes_fprop) && bdv_aligned16(y) && bdv_aligned16(workspace),
+              "bdv_conv_fprop_pl: pointers must be 16-byte aligned");
+  Geom g = make_geom(gg);
+  g.M = g.N * g.Ho * g.Wo;
+  g.Ktot = g.R * g.S * g.Cin;
+  BDV_REQUIRE((int64_t)3 * g.Cout * g.Ktot * 2 < (1ll << 31), "bdv_conv_fprop_pl: weight planes exceed 2^31 bytes");
+  hipStream_t s = (hipStream_t)stream;
+  const PlPlan p = plan_pl_ws(g.M, g.Cout, g.Ktot / BK, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, true);
+  BDV_REQUIRE(p.cfg >= 0, "bdv_conv_fprop_pl: no tile configuration for Cout=%d", g.Cout);
+  // bn_partial has one row per row tile of THIS kernel: bdv_conv_fprop_pl_stat_rows(g)
+  const int blocks = p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split;
+  epi.MT = p.MT;
+  float* slab = (float*)workspace;
+  const unsigned short* wp = (const unsigned short*)planes_fprop;
+  if (debug_plan())
+    fprintf(stderr, "[bdv plan] fprop_pl %dx%d Cin %d Cout %d k%d s%d: cfg %d tiles %d nk %d -> dp %d rem %d split %d (est %.0f us)\n", g.H,
+            g.W, g.Cin, g.Cout, g.R, g.stride, p.cfg, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split, p.est_us);
+#define BDV_FPROP_PL(BM_, BN_, WM_, WN_, NB_)                                                                                         \
+  do {                                                                                                                                \
+    hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y, g, p.NT,   \
+                       p.wk, slab, epi);                                                                                              \
+    BDV_LAUNCH_CHECK("bdv_conv_fprop_pl");                                                                                            \
+    if (p.wk.split > 1) {                                                                                                             \
+      hipLaunchKernelGGL((conv_fprop_fixup_kernel<BM_, BN_, WM_, WN_>), dim3(p.wk.rem_tiles), dim3(64 * WM_ * WN_), 0, s,             \
+                         (const float*)slab, y, g, p.NT, p.wk, epi);                                                                  \
+      BDV_LAUNCH_CHECK("bdv_conv_fprop_pl(fixup)");                                                                                   \
+    }                                                                                                                                 \
+  } while (0)
+  if (p.cfg == 0) BDV_FPROP_PL(128, 256, 2, 4, 2);
+  else if (p.cfg == 1) BDV_FPROP_PL(256, 128, 4, 2, 2);
+  else BDV_FPROP_PL(256, 256, 2, 4, 1);
+#undef BDV_FPROP_PL
+  return BDV_OK;
+}
+
+extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* planes_dgrad, float* dx, const float* add_src,
+                                 const uint32_t* add_mask_src, const bdv_conv_geom* gg, const bdv_bn_stat_fuse* bn_stat,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  if (int e = check_geom(gg, "bdv_conv_dgrad_pl")) return e;
+  if (planes_dgrad == nullptr || !pl_dgrad_ok(gg))
+    return conv_dgrad_impl(dy, w, nullptr, dx, add_src, add_mask_src, gg, bn_stat, workspace, workspace_bytes, stream);
+  BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  if (bn_stat != nullptr) {
+    BDV_REQUIRE(gg->stride == 1, "bdv_conv_dgrad_pl: fused BatchNorm statistics need stride 1");
+    BDV_REQUIRE(bn_stat->y && bn_stat->mean && bn_stat->invstd && bn_stat->partial, "bdv_conv_dgrad_pl: null pointer in bdv_bn_stat_fuse");
+    BDV_REQUIRE(bdv_aligned16(bn_stat->y) && bdv_aligned16(bn_stat->mean) && bdv_aligned16(bn_stat->invstd) &&
+                    bdv_aligned16(bn_stat->partial), "bdv_conv_dgrad_pl: bdv_bn_stat_fuse pointers must be 16-byte aligned");
+    BDV_REQUIRE(bn_stat->relu_mask == nullptr || gg->Cin % 32 == 0, "bdv_conv_dgrad_pl: a ReLU mask needs Cin %% 32 == 0");
+    stat.y = bn_stat->y;
+    stat.mask = bn_stat->relu_mask;
+    stat.mean = bn_stat->mean;
+    stat.invstd = bn_stat->invstd;
+    stat.partial = bn_stat->partial;
+  }
+  BDV_REQUIRE(dy && dx, "bdv_conv_dgrad_pl: null pointer");
+  BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(planes_dgrad) && bdv_aligned16(dx) && bdv_aligned16(workspace),
+              "bdv_conv_dgrad_pl: pointers must be 16-byte aligned");
+  BDV_REQUIRE(add_src != nullptr || add_mask_src == nullptr, "bdv_conv_dgrad_pl: add_mask_src without add_src");
+  Geom g = make_geom(gg);
+  g.M = g.N * g.H * g.W;
+  g.Ktot = g.R * g.S * g.Cout;
+  BDV_REQUIRE((int64_t)3 * g.Cin * g.Ktot * 2 < (1ll << 31), "bdv_conv_dgrad_pl: weight planes exceed 2^31 bytes");
+  hipStream_t s = (hipStream_t)stream;
+  const int st = g.stride;
+  const int Mc0 = g.N * ((g.H + st - 1) / st) * ((g.W + st - 1) / st);  // largest parity class
+  PlPlan p = plan_pl_ws(st == 1 ? g.M : Mc0, g.Cin, g.Ktot / BK,
+                        workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, st == 1);
+  BDV_REQUIRE(p.cfg >= 0, "bdv_conv_dgrad_pl: no tile configuration for Cin=%d", g.Cin);
+  if (st != 1) p.wk.dp_tiles = ((p.MT + 7) / 8) * 8 * p.NT;  // padded grid per parity class
+  // the statistics partial has one row per row tile of THIS kernel
+  stat.MT = p.MT;
+  const dim3 grid(p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split, st * st);
+  float* slab = (float*)workspace;
+  const unsigned short* dp = (const unsigned short*)planes_dgrad;
+  if (debug_plan())
+    fprintf(stderr, "[bdv plan] dgrad_pl %dx%d Cin %d Cout %d k%d s%d: cfg %d tiles %d nk %d -> dp %d rem %d split %d (est %.0f us)\n", g.H,
+            g.W, g.Cin, g.Cout, g.R, g.stride, p.cfg, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split, p.est_us);
+#define BDV_DGRAD_PL(BM_, BN_, WM_, WN_, NB_)                                                                                          \
+  do {                                                                                                                                 \
+    hipLaunchKernelGGL((conv_dgrad_pl_kernel<BM_, BN_, WM_, WN_, NB_>), grid, dim3(64 * WM_ * WN_), 0, s, dy, dp, dx, add_src,          \
+                       add_mask_src, g, p.NT, p.wk, slab, stat);                                                                       \
+    BDV_LAUNCH_CHECK("bdv_conv_dgrad_pl");                                                                                             \
+    if (p.wk.split > 1) {                                                                                                              \
+      hipLaunchKernelGGL((conv_dgrad_fixup_kernel<BM_, BN_, WM_, WN_>), dim3(p.wk.rem_tiles), dim3(64 * WM_ * WN_), 0, s,              \
+                         (const float*)slab, dx, add_src, add_mask_src, g, p.NT, p.wk, stat);                                          \
+      BDV_LAUNCH_CHECK("bdv_conv_dgrad_pl(fixup)");                                                                                    \
+    }                                                                                                                                  \
+  } while (0)
+  if (p.cfg == 0) BDV_DGRAD_PL(128, 256, 2, 4, 2);
+  else if (p.cfg == 1) BDV_DGRAD_PL(256, 128, 4, 2, 2);
+  else BDV_DGRAD_PL(256, 256, 2, 4, 1);
+#undef BDV_DGRAD_PL
+  return BDV_OK;
 }
 
 namespace {

@@ -32,6 +32,8 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0):
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src)
+    from . import kernels as K
+    K.bump_weight_epoch()            # written through .data: torch's version counters did not move
 
 
 class _Bucket:

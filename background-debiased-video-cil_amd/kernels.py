@@ -91,6 +91,46 @@ def set_conv_arith(mode: str):
     return prev
 
 
+# ---- weights as bf16 planes (bdv_conv_split_weights), cached per weight tensor -----------------------------------------
+# A conv weight is cut into its hi / mid / lo planes once per value: the entry of a weight is refreshed when torch's version
+# counter of the tensor moved (any in-place torch op, load_state_dict, torch optimizers), when its storage moved, or when
+# WEIGHT_EPOCH moved -- the fused SGD kernel writes through raw pointers, which torch cannot see, so FusedSGD.step() calls
+# bump_weight_epoch().  Forward and backward of one step share the planes; a frozen teacher's planes live as long as it does.
+import weakref as _weakref
+
+WEIGHT_EPOCH = 0
+_PLANES = {}        # id(base tensor) -> [weakref, (data_ptr, version, epoch), uint8 buffer holding both layouts]
+USE_PL = _os.environ.get('BDVCIL_PL', '1') != '0'       # 0: the round-1 bf16-piece kernels (operands split in the K loop)
+
+
+def bump_weight_epoch():
+    """Tell the plane cache that weights were changed behind torch's back (raw-pointer kernels)."""
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def weight_planes(w: torch.Tensor, g: ConvGeom):
+    """(planes_fprop, planes_dgrad) of the (Cout, R, S, Cin) weight view ``w``: uint8 views of one cached buffer."""
+    base = w._base if w._base is not None else w
+    key = id(base)
+    stamp = (w.data_ptr(), base._version, WEIGHT_EPOCH)
+    ent = _PLANES.get(key)
+    if ent is not None and ent[0]() is not base:
+        ent = None                                      # the id was recycled by another tensor
+    nbytes = lib().bdv_conv_weight_planes_bytes(ctypes.byref(g))
+    if nbytes == 0:
+        check(-1, 'bdv_conv_weight_planes_bytes')
+    if ent is None or ent[1] != stamp or ent[2].numel() != 2 * nbytes:
+        buf = ent[2] if ent is not None and ent[2].numel() == 2 * nbytes and ent[2].device == w.device else \
+            torch.empty(2 * nbytes, dtype=torch.uint8, device=w.device)
+        check(lib().bdv_conv_split_weights(_p(w), ctypes.byref(g), _p(buf[:nbytes]), _p(buf[nbytes:]), _stream()),
+              'bdv_conv_split_weights')
+        ref = _weakref.ref(base, lambda _r, k=key: _PLANES.pop(k, None))
+        ent = [ref, stamp, buf]
+        _PLANES[key] = ent
+    return ent[2][:nbytes], ent[2][nbytes:]
+
+
 def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torch.Tensor] = None,
                ws_tag: str = 'conv', bn_stats: bool = False, affine=None, x3: Optional[bool] = None):
     """x (N,H,W,Cin) NHWC, w (Cout,R,S,Cin) -> y (N,Ho,Wo,Cout); with bn_stats also the fused BatchNorm partial
@@ -103,10 +143,12 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
     _chk(y, (g.N, g.Ho, g.Wo, g.Cout), name='y')
     ws = _conv_ws(g, 0, x.device, ws_tag)
     part = aff = None
+    use_x3 = FPROP_X3 if x3 is None else x3
+    use_pl = use_x3 and USE_PL and g.Cin % 32 == 0 and g.Cout % 128 == 0
     if bn_stats:
         if affine is not None:
             raise ValueError('conv_fprop: bn_stats and affine exclude each other')
-        rows = lib().bdv_conv_fprop_stat_rows(ctypes.byref(g))
+        rows = (lib().bdv_conv_fprop_pl_stat_rows if use_pl else lib().bdv_conv_fprop_stat_rows)(ctypes.byref(g))
         if rows <= 0:
             check(-1, 'bdv_conv_fprop_stat_rows')
         part = torch.empty((2, rows, g.Cout), dtype=torch.float32, device=x.device)
@@ -117,7 +159,13 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
         if res is not None:
             _chk(res, (g.N, g.Ho, g.Wo, g.Cout), name='residual')
         aff = ConvAffine(scale.data_ptr(), shift.data_ptr(), res.data_ptr() if res is not None else None, int(bool(relu)))
-    fn = lib().bdv_conv_fprop_x3 if (FPROP_X3 if x3 is None else x3) else lib().bdv_conv_fprop
+    if use_pl:
+        planes_f, _ = weight_planes(w, g)
+        check(lib().bdv_conv_fprop_pl(_p(x), _p(w), _p(planes_f), _p(y), ctypes.byref(g), _p(part),
+                                      ctypes.byref(aff) if aff is not None else None, _p(ws), ws.numel(), _stream()),
+              'bdv_conv_fprop_pl')
+        return (y, part) if bn_stats else y
+    fn = lib().bdv_conv_fprop_x3 if use_x3 else lib().bdv_conv_fprop
     check(fn(_p(x), _p(w), _p(y), ctypes.byref(g), _p(part), ctypes.byref(aff) if aff is not None else None,
              _p(ws), ws.numel(), _stream()), 'bdv_conv_fprop')
     return (y, part) if bn_stats else y
@@ -143,6 +191,8 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
     if add_mask_src is not None:
         _chk(add_mask_src, (g.N * g.H * g.W * g.Cin // 32,), dtype=torch.int32, name='add_mask_src')
     fuse = partial = None
+    use_x3 = (DGRAD_X3 if x3 is None else x3) and g.Cin % 128 == 0
+    use_pl = use_x3 and USE_PL
     if bn_stats is not None:
         y, mask, mean, invstd = bn_stats
         _chk(y, (g.N, g.H, g.W, g.Cin), name='y')
@@ -150,12 +200,20 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
         _chk(invstd, (g.Cin,), name='invstd')
         if mask is not None:
             _chk(mask, (y.numel() // 32,), dtype=torch.int32, name='relu_mask')
-        rows = lib().bdv_conv_dgrad_stat_rows(ctypes.byref(g))
+        rows = (lib().bdv_conv_dgrad_pl_stat_rows if use_pl else lib().bdv_conv_dgrad_stat_rows)(ctypes.byref(g))
+        if rows <= 0:
+            check(-1, 'bdv_conv_dgrad_stat_rows')
         partial = torch.empty((2, rows, g.Cin), dtype=torch.float32, device=dy.device)
         fuse = BnStatFuse(y.data_ptr(), mask.data_ptr() if mask is not None else None, mean.data_ptr(), invstd.data_ptr(),
                           partial.data_ptr())
     ws = _conv_ws(g, 1, dy.device, ws_tag)
-    if (DGRAD_X3 if x3 is None else x3) and g.Cin % 128 == 0:
+    if use_pl:
+        _, planes_d = weight_planes(w, g)
+        check(lib().bdv_conv_dgrad_pl(_p(dy), _p(w), _p(planes_d), _p(dx), _p(add_src), _p(add_mask_src), ctypes.byref(g),
+                                      ctypes.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), _stream()),
+              'bdv_conv_dgrad_pl')
+        return dx if bn_stats is None else (dx, partial)
+    if use_x3:
         w_t = w.permute(1, 2, 3, 0).contiguous()            # (R, S, Cin, Cout): contraction index contiguous
         check(lib().bdv_conv_dgrad_x3(_p(dy), _p(w), _p(w_t), _p(dx), _p(add_src), _p(add_mask_src), ctypes.byref(g),
                                       ctypes.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), _stream()),

@@ -132,6 +132,7 @@ class FusedSGD(torch.optim.Optimizer):
         t = self._build_tables(active)
         K.multi_sgd(t['p'], t['g'], t['b'], t['n'], t['lr'], t['wd'], len(active), momenta.pop(), self._grad_scale,
                     self._coef if self._clip_active else None)
+        K.bump_weight_epoch()        # the kernel updates the weights through raw pointers: cached bf16 planes are stale now
         self._clip_active = False
         return loss
 

@@ -107,6 +107,31 @@ int bdv_conv_dgrad_x3(const float* dy, const float* w, const float* w_t, float* 
                       const uint32_t* add_mask_src, const bdv_conv_geom* g, const bdv_bn_stat_fuse* bn_stat, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* Weights as bf16 planes for the default conv arithmetic (every fp32 product from three bf16 pieces per operand, six
+ * v_mfma_f32_32x32x16_bf16 products, fp32 accumulate; replaces the same F.conv2d / autograd call sites as bdv_conv_fprop and
+ * bdv_conv_dgrad).  bdv_conv_split_weights cuts w [Cout,R,S,Cin] once per optimizer step into hi / mid / lo planes
+ * (hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid), round to nearest), each of
+ * bdv_conv_weight_planes_bytes(g) / 3 bytes, in the two layouts the kernels stream:
+ *   planes_fprop  [piece][K-step = (ci / 32) * R*S + tap][co][ci % 32]
+ *   planes_dgrad  [piece][tap][co / 32][ci][co % 32]
+ * (either may be NULL; Cin and Cout multiples of 32).  bdv_conv_fprop_pl / bdv_conv_dgrad_pl take the planes beside w and
+ * behave like bdv_conv_fprop / bdv_conv_dgrad (same epilogues, workspace = bdv_conv_workspace_bytes); shapes their
+ * 8-wave kernels do not cover (Cout resp. Cin not a multiple of 128, the stem) run the other kernels on w.  The fused
+ * statistics partials have bdv_conv_fprop_pl_stat_rows(g) / bdv_conv_dgrad_pl_stat_rows(g) rows (one per row tile of the
+ * kernel that will run, 128 or 256 rows). */
+size_t bdv_conv_weight_planes_bytes(const bdv_conv_geom* g);
+int bdv_conv_split_weights(const float* w, const bdv_conv_geom* g, void* planes_fprop, void* planes_dgrad, void* stream);
+/* Test / A-B hook, process-wide and not thread-safe: force the tile configuration of the two entry points below
+ * (0 = 128x256, 1 = 256x128, 2 = 256x256 where the column count allows it; -1 = chosen by the planner's cost model). */
+int bdv_conv_debug_force_tile(int cfg);
+int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* g);
+int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* g);
+int bdv_conv_fprop_pl(const float* x, const float* w, const void* planes_fprop, float* y, const bdv_conv_geom* g,
+                      float* bn_partial, const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream);
+int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* planes_dgrad, float* dx, const float* add_src,
+                      const uint32_t* add_mask_src, const bdv_conv_geom* g, const bdv_bn_stat_fuse* bn_stat, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* wgrad: dw[Cout,R,S,Cin] = beta * dw + sum_pixels dy (x) shift(x).  Deterministic split-K:
  * partial slabs go to `workspace`, a second kernel reduces them in fixed order. */
 int bdv_conv_wgrad(const float* dy, const float* x, float* dw, float beta, const bdv_conv_geom* g, void* workspace,

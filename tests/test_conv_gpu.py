@@ -253,6 +253,136 @@ def test_bf16_pieces_adversarial_range(case, regime, dev):
         assert ratio <= tol[x3], (regime, 'wgrad', 'bf16x3' if x3 else 'f32mfma', ratio)
 
 
+def _bf16_pieces(w):
+    """hi / mid / lo of an fp32 tensor, round to nearest even, on the CPU."""
+    hi = w.to(torch.bfloat16)
+    r1 = w - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return hi, mid, lo
+
+
+@pytest.mark.parametrize('shape', [(128, 3, 64), (256, 1, 128), (64, 3, 32)])
+def test_split_weights_planes(shape, dev):
+    """bdv_conv_split_weights: the three bf16 pieces of every weight, bit for bit, in the two layouts the kernels stream
+    (include/bdvcil_hip.h); hi + mid + lo reproduces the fp32 value exactly."""
+    import ctypes
+    from bdvcil_amd import kernels as K
+    from bdvcil_amd._lib import lib
+    Cout, R, Cin = shape
+    g = K.make_geom(8, 8, 8, Cin, Cout, R, R, 1, R // 2)
+    w = torch.randn(Cout, R, R, Cin, generator=torch.Generator().manual_seed(3)) * 0.05
+    w[0, 0, 0, :4] = torch.tensor([0.0, 1.0, -3.0e-39, 65504.0])
+    pf, pd = K.weight_planes(w.to(dev), g)
+    n = Cout * R * R * Cin
+    assert pf.numel() == 6 * n == lib().bdv_conv_weight_planes_bytes(ctypes.byref(g))
+    pf = pf.cpu().view(torch.bfloat16).view(3, Cin // 32, R * R, Cout, 32)
+    pd = pd.cpu().view(torch.bfloat16).view(3, R * R, Cout // 32, Cin, 32)
+    pieces = _bf16_pieces(w)
+    for k, piece in enumerate(pieces):
+        want_f = piece.view(Cout, R * R, Cin // 32, 32).permute(2, 1, 0, 3)          # [chunk][tap][co][32 ci]
+        want_d = piece.view(Cout // 32, 32, R * R, Cin).permute(2, 0, 3, 1)          # [tap][co chunk][ci][32 co]
+        assert torch.equal(pf[k].view(torch.int16), want_f.contiguous().view(torch.int16)), k
+        assert torch.equal(pd[k].view(torch.int16), want_d.contiguous().view(torch.int16)), k
+    back = pieces[0].float() + pieces[1].float() + pieces[2].float()
+    normal = w.abs() > 1e-30
+    assert torch.equal(back[normal], w[normal])
+
+
+def test_weight_plane_cache_follows_the_weights(dev):
+    """The cached planes are refreshed when the weights change: through a torch in-place op (version counter), through the
+    fused SGD kernel (raw pointers: FusedSGD.step bumps the epoch), and not otherwise."""
+    import bdvcil_amd as bd
+    from bdvcil_amd import functional as Fn
+    from bdvcil_amd import kernels as K
+    g = K.make_geom(8, 8, 8, 64, 128, 1, 1, 1, 0)
+    x = torch.randn(8, 8, 8, 64, generator=torch.Generator().manual_seed(1)).to(dev)
+    w0 = (torch.randn(128, 64, 1, 1, generator=torch.Generator().manual_seed(2)) * 0.1).to(dev)
+    wparam = torch.nn.Parameter(w0.contiguous(memory_format=torch.channels_last))          # OIHW parameter, as in the model
+    y0 = K.conv_fprop(x, Fn.weight_krsc(wparam), g, x3=True)
+    assert torch.equal(K.conv_fprop(x, Fn.weight_krsc(wparam), g, x3=True), y0)
+    ptr = K.weight_planes(Fn.weight_krsc(wparam), g)[0].data_ptr()
+    epoch = K.WEIGHT_EPOCH
+    assert K.weight_planes(Fn.weight_krsc(wparam), g)[0].data_ptr() == ptr and len([k for k in K._PLANES if k == id(wparam)]) == 1
+    with torch.no_grad():
+        wparam.mul_(2.0)                                                      # torch in-place op: version counter moves
+    assert torch.equal(K.conv_fprop(x, Fn.weight_krsc(wparam), g, x3=True), 2 * y0)
+    opt = bd.FusedSGD([wparam], lr=0.5, momentum=0.0, weight_decay=0.0)
+    wparam.grad = wparam.detach().clone()                                     # w <- w - 0.5 w: back to the first values
+    opt.step()
+    assert K.WEIGHT_EPOCH == epoch + 1
+    assert torch.equal(K.conv_fprop(x, Fn.weight_krsc(wparam), g, x3=True), y0)
+    key = id(wparam)
+    del wparam, opt
+    import gc
+    gc.collect()
+    assert key not in K._PLANES                                               # the planes die with the weight
+
+
+PL_CASES = [
+    (16, 14, 14, 128, 256, 1, 1, 0, 8, 16),     # 1x1 + shift, Cout 256
+    (8, 9, 9, 128, 256, 3, 1, 1, 1, 0),         # 3x3, odd size, ragged M (648 rows)
+    (8, 8, 8, 256, 512, 3, 2, 1, 8, 32),        # 3x3 stride 2 + shift
+    (16, 7, 7, 256, 128, 1, 1, 0, 8, 32),       # Cout 128: 256x128 tiles
+    (4, 10, 10, 128, 128, 3, 1, 1, 1, 0),
+    (8, 8, 8, 256, 256, 1, 2, 0, 1, 0),         # 1x1 stride 2 (downsample)
+]
+
+
+@pytest.mark.parametrize('case', PL_CASES)
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2])
+def test_plane_kernels_every_tile(case, tile, dev):
+    """The 8-wave kernels on pre-split weight planes (bdv_conv_fprop_pl / bdv_conv_dgrad_pl), every tile configuration
+    forced in turn (-1 = planner's choice): against the CPU reference (2e-5), against the fp32-MFMA kernels (4e-6), with the
+    fused BatchNorm statistics, the folded eval BatchNorm, the residual / mask add and the BatchNorm-backward statistics."""
+    from bdvcil_amd import kernels as K
+    from bdvcil_amd._lib import check, lib
+    N, H, W, Cin, Cout, R, st, pad, T, fold = case
+    x, w = _mk(case, 21)
+    x.requires_grad_(True)
+    y = _ref(x, w, st, pad, T, fold)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(22))
+    y.backward(dy)
+    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    check(lib().bdv_conv_debug_force_tile(tile), 'force_tile')
+    try:
+        y3, part3 = K.conv_fprop(xd, wd, g, bn_stats=True, x3=True)
+        y1, part1 = K.conv_fprop(xd, wd, g, bn_stats=True, x3=False)
+        _close(y3.cpu(), y.detach().permute(0, 2, 3, 1))
+        _close(y3, y1, tol=4e-6)
+        _close(part3.sum(1), part1.sum(1), tol=2e-5)
+        assert torch.equal(K.conv_fprop(xd, wd, g, x3=True), y3)
+        scale, shift = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
+        res = torch.randn_like(y1)
+        _close(K.conv_fprop(xd, wd, g, affine=(scale, shift, res, True), x3=True),
+               K.conv_fprop(xd, wd, g, affine=(scale, shift, res, True), x3=False), tol=1e-5)
+        gen = torch.Generator().manual_seed(23)
+        add = torch.randn(N, H, W, Cin, generator=gen)
+        m = torch.randn(N, H, W, Cin, generator=gen) > 0
+        bits = torch.from_numpy(np.packbits(m.numpy().reshape(-1), bitorder='little').view(np.int32).copy()).to(dev)
+        want = x.grad.permute(0, 2, 3, 1) + add * m
+        d3 = K.conv_dgrad(dyd, wd, g, add_src=add.to(dev), add_mask_src=bits, x3=True)
+        d1 = K.conv_dgrad(dyd, wd, g, add_src=add.to(dev), add_mask_src=bits, x3=False)
+        _close(d3.cpu(), want)
+        _close(d3, d1, tol=4e-6)
+        if st == 1:          # BatchNorm-backward statistics of the tensor dx feeds, taken in the epilogue
+            yprev = torch.randn(N, H, W, Cin, generator=gen).to(dev)
+            gamma = (torch.rand(Cin, generator=gen) + 0.5).to(dev)
+            mean, invstd, sc, sh = K.bn_train_stats(yprev, gamma, torch.zeros(Cin, device=dev), 1e-5, 0.1, None, None)
+            _, mask = K.bn_apply(yprev, sc, sh, None, True, want_mask=True)
+            dxs, part = K.conv_dgrad(dyd, wd, g, add_src=add.to(dev), add_mask_src=bits, bn_stats=(yprev, mask, mean, invstd), x3=True)
+            assert torch.equal(dxs, d3)
+            a = K.bn_backward(d3, mask, yprev, gamma, mean, invstd, True)
+            b = K.bn_backward(d3, mask, yprev, gamma, mean, invstd, True, stat_partial=part)
+            for u, v in zip(a, b):
+                _close(u, v, tol=2e-5)
+    finally:
+        check(lib().bdv_conv_debug_force_tile(-1), 'force_tile')
+
+
 def test_wgrad_partial_and_batched_reduce(dev):
     """Weight gradients left as split-K partial products and reduced together in one launch (what a stage's backward does)
     equal the one-call form bit for bit, for a batch of layers of very different sizes."""
@@ -380,7 +510,7 @@ def test_dgrad_fused_bn_backward_statistics(case, relu, dev, conv_arith):
     dx, part = K.conv_dgrad(dy, wd, g, add_src=add, bn_stats=(yprev, mask, mean, invstd))
     torch.cuda.synchronize()
     assert torch.equal(dx, dx_ref)
-    assert part.shape == (2, (N * H * W + 127) // 128, Cin)
+    assert part.shape[0] == 2 and part.shape[2] == Cin and part.shape[1] in ((N * H * W + 127) // 128, (N * H * W + 255) // 256)
     gm = dx_ref.double().cpu()
     if relu:
         bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), bitorder='little').astype(bool).reshape(N, H, W, Cin)
