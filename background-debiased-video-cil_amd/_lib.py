@@ -63,6 +63,8 @@ SIGNATURES = {
     'bdv_conv_wgrad_splits': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_wgrad_partial': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_conv_wgrad_partial_x3': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, P]),
+    'bdv_conv_wgrad_pl_splits': (c_int, [POINTER(ConvGeom)]),
+    'bdv_conv_wgrad_partial_pl': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_wgrad_reduce_batched': (c_int, [P, P, P, P, c_int, c_float, P]),
     'bdv_bn_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'bdv_bn_train_stats': (c_int, [P, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_size_t, P]),

@@ -69,24 +69,26 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-// Fixed-order column sum of two [RB][C] fp32 slabs in fp64: 4 channels x 64 row-lanes per block.
+// Fixed-order column sum of two [RB][C] fp32 slabs in fp64: 4 channels x FIN_LANES row-lanes per block (1024 threads).
+// The loop is a chain of dependent-latency loads (up to 25 088 partial rows for the stem), so the rows are spread over 256
+// lanes per channel with four independent chains each; the lane sums are combined in a fixed order (16 groups of 16).
+constexpr int FIN_LANES = 256;
+
 __device__ __forceinline__ void slab_colsum2(const float* __restrict__ a, const float* __restrict__ b, int RB, int C, int c,
-                                             int rl, double (*sh)[64][5], double& sa, double& sb) {
+                                             int rl, double (*sh)[FIN_LANES][5], double& sa, double& sb) {
   double x = 0.0, y = 0.0;
   if (c < C) {
-    // four independent chains per lane keep 8 loads in flight (the loop is latency-bound: up to 392 rows per lane for
-    // the stem); the chains are combined in a fixed order
     double x1 = 0.0, x2 = 0.0, x3 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
     int r = rl;
-    for (; r + 192 < RB; r += 256) {
-      const float a0 = a[(int64_t)r * C + c], a1 = a[(int64_t)(r + 64) * C + c];
-      const float a2 = a[(int64_t)(r + 128) * C + c], a3 = a[(int64_t)(r + 192) * C + c];
-      const float b0 = b[(int64_t)r * C + c], b1 = b[(int64_t)(r + 64) * C + c];
-      const float b2 = b[(int64_t)(r + 128) * C + c], b3 = b[(int64_t)(r + 192) * C + c];
+    for (; r + 3 * FIN_LANES < RB; r += 4 * FIN_LANES) {
+      const float a0 = a[(int64_t)r * C + c], a1 = a[(int64_t)(r + FIN_LANES) * C + c];
+      const float a2 = a[(int64_t)(r + 2 * FIN_LANES) * C + c], a3 = a[(int64_t)(r + 3 * FIN_LANES) * C + c];
+      const float b0 = b[(int64_t)r * C + c], b1 = b[(int64_t)(r + FIN_LANES) * C + c];
+      const float b2 = b[(int64_t)(r + 2 * FIN_LANES) * C + c], b3 = b[(int64_t)(r + 3 * FIN_LANES) * C + c];
       x += (double)a0; x1 += (double)a1; x2 += (double)a2; x3 += (double)a3;
       y += (double)b0; y1 += (double)b1; y2 += (double)b2; y3 += (double)b3;
     }
-    for (; r < RB; r += 64) {
+    for (; r < RB; r += FIN_LANES) {
       x += (double)a[(int64_t)r * C + c];
       y += (double)b[(int64_t)r * C + c];
     }
@@ -97,23 +99,36 @@ __device__ __forceinline__ void slab_colsum2(const float* __restrict__ a, const 
   sh[0][rl][cl] = x;
   sh[1][rl][cl] = y;
   __syncthreads();
+  double u = 0.0, v = 0.0;
+  if (rl < 16) {  // lane rl sums lanes 16 rl .. 16 rl + 15, in order
+    for (int k = 0; k < 16; ++k) {
+      u += sh[0][16 * rl + k][cl];
+      v += sh[1][16 * rl + k][cl];
+    }
+  }
+  __syncthreads();
+  if (rl < 16) {
+    sh[0][rl][cl] = u;
+    sh[1][rl][cl] = v;
+  }
+  __syncthreads();
   sa = 0.0;
   sb = 0.0;
   if (rl == 0) {
-    for (int k = 0; k < 64; ++k) {
+    for (int k = 0; k < 16; ++k) {
       sa += sh[0][k][cl];
       sb += sh[1][k][cl];
     }
   }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int RB,
+__global__ __launch_bounds__(4 * FIN_LANES) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int RB,
                                                            int64_t M, int C, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float momentum,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                            float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double sh[2][64][5];
+  __shared__ double sh[2][FIN_LANES][5];
   const int c = blockIdx.x * 4 + (threadIdx.x & 3), rl = threadIdx.x >> 2;
   double s, q;
   slab_colsum2(psum, psq, RB, C, c, rl, sh, s, q);
@@ -246,11 +261,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 
 // coef[0][c] = gamma*invstd, coef[1][c] = sum(g)/M, coef[2][c] = sum(g*xhat)/M
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int RB,
+__global__ __launch_bounds__(4 * FIN_LANES) void bn_bwd_finalize_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int RB,
                                                                int64_t M, int C, const float* __restrict__ gamma,
                                                                const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float beta_acc, float* __restrict__ coef) {
-  __shared__ double sh[2][64][5];
+  __shared__ double sh[2][FIN_LANES][5];
   const int c = blockIdx.x * 4 + (threadIdx.x & 3), rl = threadIdx.x >> 2;
   double s1, s2;
   slab_colsum2(p1, p2, RB, C, c, rl, sh, s1, s2);
@@ -411,7 +426,7 @@ extern "C" int bdv_bn_train_stats(const float* y, int64_t M, int C, const float*
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_partial_kernel, dim3(b.RB, b.CC), dim3(256), 0, s, y, psum, psq, M, C, b.CVB, b.RL, b.rows_per_block);
   BDV_LAUNCH_CHECK("bdv_bn_train_stats(partial)");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)psum, (const float*)psq, b.RB,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(4 * FIN_LANES), 0, s, (const float*)psum, (const float*)psq, b.RB,
                      M, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
   BDV_LAUNCH_CHECK("bdv_bn_train_stats(finalize)");
   return BDV_OK;
@@ -423,7 +438,7 @@ extern "C" int bdv_bn_train_finalize(const float* partial, int rows, int64_t M, 
   BDV_REQUIRE(partial && gamma && beta && save_mean && save_invstd && scale && shift, "bdv_bn_train_finalize: null pointer");
   BDV_REQUIRE(rows > 0 && M > 0 && C > 0 && C % 4 == 0, "bdv_bn_train_finalize: bad shape");
   BDV_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bdv_bn_train_finalize: running stats must come in pairs");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(4 * FIN_LANES), 0, (hipStream_t)stream, partial,
                      partial + (size_t)rows * C, rows, M, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
                      save_invstd, scale, shift);
   BDV_LAUNCH_CHECK("bdv_bn_train_finalize");
@@ -498,7 +513,7 @@ extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, con
                          save_invstd, p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
     BDV_LAUNCH_CHECK("bdv_bn_backward(partial)");
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, q1, q2, rows, M, C, gamma, save_invstd, dgamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(4 * FIN_LANES), 0, s, q1, q2, rows, M, C, gamma, save_invstd, dgamma,
                      dbeta, beta_acc, coef);
   BDV_LAUNCH_CHECK("bdv_bn_backward(finalize)");
   const int64_t n4 = M * C / 4;
@@ -546,7 +561,7 @@ extern "C" int bdv_bn_backward_maxpool(const float* dpool, const uint8_t* pool_i
                      (const float4*)y, (const float4*)save_mean, (const float4*)save_invstd, (const float4*)nullptr,
                      (float4*)nullptr, p1, p2, N, H, W, CV, Ho, Wo);
   BDV_LAUNCH_CHECK("bdv_bn_backward_maxpool(partial)");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, (const float*)p1, (const float*)p2, gx * gy, M, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(4 * FIN_LANES), 0, s, (const float*)p1, (const float*)p2, gx * gy, M, C,
                      gamma, save_invstd, dgamma, dbeta, beta_acc, coef);
   BDV_LAUNCH_CHECK("bdv_bn_backward_maxpool(finalize)");
   hipLaunchKernelGGL((bn_bwd_pool_kernel<true>), grid, blk, 0, s, (const float4*)dpool, (const uchar4*)pool_idx, relu_mask,

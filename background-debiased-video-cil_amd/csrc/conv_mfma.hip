@@ -1708,24 +1708,28 @@ __device__ __forceinline__ void pl_split_store(unsigned char* __restrict__ base,
 }
 
 // 32-deep K-step on one stage: wave (wm, wn) owns rows 32 WM i + 32 wm + r and columns 32 WN j + 32 wn + c (interleaved
-// tiling, as the epilogues expect)
+// tiling, as the epilogues expect).  fa[s] / fb[s] are the lane's byte offsets of its fragment of 16-deep step s in tile 0 of
+// plane 0 (pl_frag_off); every other fragment of the stage is a compile-time constant away (the swizzle term only depends on
+// (row >> 2) & 3, which multiples of 32 rows do not change), so the reads carry immediate offsets.
+__device__ __forceinline__ int pl_frag_off(int row0, int s, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  return pl_off(row0 + r, 2 * s + h);
+}
+
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void mma_stage_pl(const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs,
-                                             f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn, int lane) {
+                                             f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const int (&fa)[2], const int (&fb)[2]) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int PA = BM * 64, PB = BN * 64;
-  const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int s = 0; s < BK / 16; ++s) {
     bf16x8_t a[3][TM], b[3][TN];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a[p][i] = *reinterpret_cast<const bf16x8_t*>(As + p * PA + pl_off(32 * WM * i + 32 * wm + r, 2 * s + h));
+      for (int i = 0; i < TM; ++i) a[p][i] = *reinterpret_cast<const bf16x8_t*>(As + fa[s] + (p * PA + 32 * WM * i * 64));
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b[p][j] = *reinterpret_cast<const bf16x8_t*>(Bs + p * PB + pl_off(32 * WN * j + 32 * wn + r, 2 * s + h));
+      for (int j = 0; j < TN; ++j) b[p][j] = *reinterpret_cast<const bf16x8_t*>(Bs + fb[s] + (p * PB + 32 * WN * j * 64));
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1739,6 +1743,19 @@ __device__ __forceinline__ void mma_stage_pl(const unsigned char* __restrict__ A
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
       }
   }
+}
+
+// fp32 x 4 -> the three planes of a stage image at the thread's precomputed byte offset `off` (+ a constant row offset)
+__device__ __forceinline__ void pl_split_store_at(unsigned char* __restrict__ q, int plane_bytes, const float4 v) {
+  const f32x4_t a = {v.x, v.y, v.z, v.w};
+  const bf16x4_t hi = __builtin_convertvector(a, bf16x4_t);
+  const f32x4_t r1 = a - __builtin_convertvector(hi, f32x4_t);
+  const bf16x4_t mid = __builtin_convertvector(r1, bf16x4_t);
+  const f32x4_t r2 = r1 - __builtin_convertvector(mid, f32x4_t);
+  const bf16x4_t lo = __builtin_convertvector(r2, bf16x4_t);
+  *reinterpret_cast<bf16x4_t*>(q) = hi;
+  *reinterpret_cast<bf16x4_t*>(q + plane_bytes) = mid;
+  *reinterpret_cast<bf16x4_t*>(q + 2 * plane_bytes) = lo;
 }
 
 // ---- weights -> bf16 planes ------------------------------------------------------------------
@@ -1799,46 +1816,55 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
   float* const smem = reinterpret_cast<float*>(smem_b);
 
   const int nk = g.Ktot / BK;
-  const WorkItem it = get_work(blockIdx.x, wk, nk);
-  const int mt = it.tile / NT, nt = it.tile - mt * NT;
-
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int arow = tid >> 3, kg = tid & 7;
   const int brow = tid >> 2, bc = tid & 3;
   const int HoWo = g.Ho * g.Wo;
+  const int RS = g.R * g.S;
   const int frame_bytes = g.H * g.W * g.Cin * 4;
   const int plane_bytes = g.Cout * g.Ktot * 2;
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * frame_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 3 * plane_bytes, 0x00020000);
 
-  int a_base[AP], a_t[AP], a_hi0[AP], a_wi0[AP];
-#pragma unroll
-  for (int p = 0; p < AP; ++p) {
-    const int m = mt * BM + arow + (NTHR / 8) * p;
-    const bool ok = m < g.M;
-    int n, rem, ho, wo;
-    fast_divmod(ok ? m : 0, HoWo, g.rcp_HoWo, n, rem);
-    fast_divmod(rem, g.Wo, g.rcp_Wo, ho, wo);
-    a_t[p] = n % g.T;
-    a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);  // rows past M fail every bounds test
-    a_wi0[p] = wo * g.stride - g.pad;
-    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad) * g.Cin * 4 + 16 * kg;
-  }
-  int b_base[BPP];
-#pragma unroll
-  for (int q = 0; q < BPP; ++q) b_base[q] = (nt * BN + brow + (NTHR / 4) * q) * 64 + 16 * bc;
+  // The workgroup is persistent: it walks the work items v = blockIdx.x, + gridDim.x, ... (one workgroup per CU, so a short
+  // K loop cannot hide its prologue and its epilogue behind another workgroup's MFMAs; instead the first loads of the next
+  // tile are issued before the epilogue of the current one, and the epilogue's stores drain while the next tile computes).
+  const int total = wk.dp_tiles + wk.rem_tiles * wk.split;
+  int v = blockIdx.x;
+  if (v >= total) return;
 
-  // K index state (uniform): K-step kt = chunk * R*S + r * S + s; the weight planes are stored in this order
-  const int RS = g.R * g.S;
-  int chunk = it.kb / RS, r, s, kt_w = it.kb;
-  {
+  WorkItem it;
+  int mt, nt;
+  int a_base[AP], a_t[AP], a_hi0[AP], a_wi0[AP];
+  int b_base[BPP];
+  int chunk, r, s, kt_w;   // K index state (uniform): K-step kt = chunk * R*S + r * S + s; the weight planes are stored in this order
+  auto setup = [&](int vv) {
+    it = get_work(vv, wk, nk);
+    mt = it.tile / NT;
+    nt = it.tile - mt * NT;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const int m = mt * BM + arow + (NTHR / 8) * p;
+      const bool ok = m < g.M;
+      int n, rem, ho, wo;
+      fast_divmod(ok ? m : 0, HoWo, g.rcp_HoWo, n, rem);
+      fast_divmod(rem, g.Wo, g.rcp_Wo, ho, wo);
+      a_t[p] = n % g.T;
+      a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);  // rows past M fail every bounds test
+      a_wi0[p] = wo * g.stride - g.pad;
+      a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad) * g.Cin * 4 + 16 * kg;
+    }
+#pragma unroll
+    for (int q = 0; q < BPP; ++q) b_base[q] = (nt * BN + brow + (NTHR / 4) * q) * 64 + 16 * bc;
+    chunk = it.kb / RS;
     const int tap = it.kb - chunk * RS;
     r = tap / g.S;
     s = tap - r * g.S;
-  }
+    kt_w = it.kb;
+  };
 
   float4 ra[AP];
   u32x4 rb[3 * BPP];
@@ -1848,9 +1874,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
     const int koff_b = kt_w * g.Cout * 64;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const bool v = (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W &&
-                     (unsigned)(a_t[p] + cls) < (unsigned)g.T;
-      ra[p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB), 0);
+      const bool ok = (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W &&
+                      (unsigned)(a_t[p] + cls) < (unsigned)g.T;
+      ra[p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (ok ? 0 : kOOB), 0);
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
@@ -1865,53 +1891,73 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
     r = wr_ ? 0 : r;
     chunk += wr_;
   };
+  // LDS offsets of this thread: stores (rows arow + 64 p / brow + 128 q keep (row >> 2) & 3) and fragment reads
+  const int st_a = pl_off(arow, kg >> 1) + 8 * (kg & 1), st_b = pl_off(brow, bc);
+  const int fa[2] = {pl_frag_off(32 * wm, 0, lane), pl_frag_off(32 * wm, 1, lane)};
+  const int fb[2] = {pl_frag_off(32 * wn, 0, lane), pl_frag_off(32 * wn, 1, lane)};
   auto store = [&](int stage) {
     unsigned char* const As = smem_b + stage * STAGE;
     unsigned char* const Bs = As + 3 * PA;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) pl_split_store(As, PA, arow + (NTHR / 8) * p, kg, ra[p]);
+    for (int p = 0; p < AP; ++p) pl_split_store_at(As + st_a + (NTHR / 8) * p * 64, PA, ra[p]);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + pl * PB + pl_off(brow + (NTHR / 4) * q, bc)) = rb[pl * BPP + q];
+      for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + st_b + (pl * PB + (NTHR / 4) * q * 64)) = rb[pl * BPP + q];
   };
-  f32x16 acc[TM][TN];
-  zero_acc<TM, TN>(acc);
 
-  if constexpr (NBUF == 2) {
+  setup(v);
+  load();
+  while (true) {
+    const int ke = it.ke, cur_mt = mt, cur_nt = nt, cur_pslot = it.pslot;
     int kt = it.kb;
-    load();
-    store(0);
-    if (kt + 1 < it.ke) load();
-    __syncthreads();
-    while (true) {
-      mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, wm, wn, lane);
-      if (kt + 1 < it.ke) store(1);
-      if (kt + 2 < it.ke) load();
-      __syncthreads();
-      if (++kt >= it.ke) break;
-      mma_stage_pl<BM, BN, WM, WN>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, wm, wn, lane);
-      if (kt + 1 < it.ke) store(0);
-      if (kt + 2 < it.ke) load();
-      __syncthreads();
-      if (++kt >= it.ke) break;
-    }
-  } else {
-    load();
-    for (int kt = it.kb; kt < it.ke; ++kt) {
-      __syncthreads();
-      store(0);
-      __syncthreads();
-      if (kt + 1 < it.ke) load();
-      mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, wm, wn, lane);
-    }
-  }
+    f32x16 acc[TM][TN];
+    zero_acc<TM, TN>(acc);
 
-  if (it.pslot >= 0) {
-    store_partial<TM, TN, NTHR>(slab, it.pslot, acc, tid);
-    return;
+    if constexpr (NBUF == 2) {
+      store(0);
+      if (kt + 1 < ke) load();
+      __syncthreads();
+      while (true) {
+        mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
+        if (kt + 1 < ke) store(1);
+        if (kt + 2 < ke) load();
+        __syncthreads();
+        if (++kt >= ke) break;
+        mma_stage_pl<BM, BN, WM, WN>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, fa, fb);
+        if (kt + 1 < ke) store(0);
+        if (kt + 2 < ke) load();
+        __syncthreads();
+        if (++kt >= ke) break;
+      }
+    } else {
+      for (; kt < ke; ++kt) {
+        __syncthreads();
+        store(0);
+        __syncthreads();
+        if (kt + 1 < ke) load();
+        mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
+      }
+    }
+
+    v += gridDim.x;
+    const bool more = v < total;
+    constexpr bool EARLY = TM * TN <= 4;   // register budget: not with 128 accumulator registers
+    if (EARLY && more) {  // first loads of the next work item: in flight during the epilogue
+      setup(v);
+      load();
+    }
+    if (cur_pslot >= 0)
+      store_partial<TM, TN, NTHR>(slab, cur_pslot, acc, tid);
+    else
+      fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, cur_mt, cur_nt, tid);
+    if (!more) break;
+    if (!EARLY) {
+      setup(v);
+      load();
+    }
+    __syncthreads();  // the epilogue is done with the staging area before the next tile's stage stores
   }
-  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
 }
 
 // ---- dgrad ------------------------------------------------------------------------------------
@@ -1946,24 +1992,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
   const int ntap = nr * ns;
   const int nk = ntap * g.Cout / BK;  // 0 for a class no filter tap reaches (e.g. 1x1 stride 2, odd pixels)
 
-  int mt, nt;
-  WorkItem it;
-  if (st == 1) {
-    it = get_work(blockIdx.x, wk, nk);
-    mt = it.tile / NT;
-    nt = it.tile - mt * NT;
-  } else {  // parity classes have different sizes: padded grid, no K split
-    const int id = blockIdx.x;
-    const int xcd = id & 7, jj = id >> 3;
-    mt = (jj / NT) * 8 + xcd;
-    nt = jj % NT;
-    if (mt >= MT) return;
-    it.tile = 0;
-    it.kb = 0;
-    it.ke = nk;
-    it.pslot = -1;
-  }
-
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -1971,35 +1999,57 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
   const int brow = tid >> 2, bc = tid & 3;
   const int HcWc = Hc * Wc;
   const int RS = g.R * g.S;
+  const int nchunk = g.Cout / BK;
   const int plane_bytes = g.Cout * RS * g.Cin * 2;
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.N * g.Ho * g.Wo * g.Cout * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)dp, 0, 3 * plane_bytes, 0x00020000);
 
-  int a_base[AP], a_h[AP], a_w[AP];
-#pragma unroll
-  for (int p = 0; p < AP; ++p) {
-    const int m = mt * BM + arow + (NTHR / 8) * p;
-    const bool ok = m < Mc;
-    const int mm = ok ? m : 0;
-    const int n = mm / HcWc;
-    const int rem = mm - n * HcWc;
-    const int hc = rem / Wc, wc = rem - hc * Wc;
-    a_h[p] = ok ? hc + bh : -(1 << 20);
-    a_w[p] = wc + bw;
-    a_base[p] = ((n * g.Ho + hc + bh) * g.Wo + wc + bw) * g.Cout * 4 + 16 * kg;
-  }
-  int b_base[BPP];
-#pragma unroll
-  for (int q = 0; q < BPP; ++q) b_base[q] = (nt * BN + brow + (NTHR / 4) * q) * 64 + 16 * bc;
+  // persistent over the work items of a stride-1 launch (see conv_fprop_pl_kernel); the parity classes of a stride-2 launch
+  // have different sizes and keep one (padded) grid entry per tile
+  const int total = st == 1 ? wk.dp_tiles + wk.rem_tiles * wk.split : (int)gridDim.x;
+  int v = blockIdx.x;
+  if (v >= total) return;
 
-  // K index state (uniform): kt = chunk * ntap + ir * ns + is  (tap-fastest)
-  int chunk = ntap > 0 ? it.kb / ntap : 0, ir, is;
-  {
+  WorkItem it;
+  int mt, nt;
+  int a_base[AP], a_h[AP], a_w[AP];
+  int b_base[BPP];
+  int chunk, ir, is;  // K index state (uniform): kt = chunk * ntap + ir * ns + is  (tap-fastest)
+  auto setup = [&](int vv) -> bool {
+    if (st == 1) {
+      it = get_work(vv, wk, nk);
+      mt = it.tile / NT;
+      nt = it.tile - mt * NT;
+    } else {
+      const int xcd = vv & 7, jj = vv >> 3;
+      mt = (jj / NT) * 8 + xcd;
+      nt = jj % NT;
+      if (mt >= MT) return false;
+      it.tile = 0;
+      it.kb = 0;
+      it.ke = nk;
+      it.pslot = -1;
+    }
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const int m = mt * BM + arow + (NTHR / 8) * p;
+      const bool ok = m < Mc;
+      const int mm = ok ? m : 0;
+      const int n = mm / HcWc;
+      const int rem = mm - n * HcWc;
+      const int hc = rem / Wc, wc = rem - hc * Wc;
+      a_h[p] = ok ? hc + bh : -(1 << 20);
+      a_w[p] = wc + bw;
+      a_base[p] = ((n * g.Ho + hc + bh) * g.Wo + wc + bw) * g.Cout * 4 + 16 * kg;
+    }
+#pragma unroll
+    for (int q = 0; q < BPP; ++q) b_base[q] = (nt * BN + brow + (NTHR / 4) * q) * 64 + 16 * bc;
+    chunk = ntap > 0 ? it.kb / ntap : 0;
     const int ct = ntap > 0 ? it.kb - chunk * ntap : 0;
     ir = ns > 0 ? ct / ns : 0;
     is = ct - ir * ns;
-  }
-  const int nchunk = g.Cout / BK;
+    return true;
+  };
 
   float4 ra[AP];
   u32x4 rb[3 * BPP];
@@ -2009,8 +2059,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
     const int koff_b = (tap * nchunk + chunk) * g.Cin * 64;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const bool v = (unsigned)(a_h[p] - ir) < (unsigned)g.Ho && (unsigned)(a_w[p] - is) < (unsigned)g.Wo;
-      ra[p] = buf_load16(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB), 0);
+      const bool ok = (unsigned)(a_h[p] - ir) < (unsigned)g.Ho && (unsigned)(a_w[p] - is) < (unsigned)g.Wo;
+      ra[p] = buf_load16(yr, (a_base[p] + koff_a) | (ok ? 0 : kOOB), 0);
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
@@ -2024,61 +2074,286 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
     ir = w2 ? 0 : ir;
     chunk += w2;
   };
+  // LDS offsets of this thread: stores (rows arow + 64 p / brow + 128 q keep (row >> 2) & 3) and fragment reads
+  const int st_a = pl_off(arow, kg >> 1) + 8 * (kg & 1), st_b = pl_off(brow, bc);
+  const int fa[2] = {pl_frag_off(32 * wm, 0, lane), pl_frag_off(32 * wm, 1, lane)};
+  const int fb[2] = {pl_frag_off(32 * wn, 0, lane), pl_frag_off(32 * wn, 1, lane)};
   auto store = [&](int stage) {
     unsigned char* const As = smem_b + stage * STAGE;
     unsigned char* const Bs = As + 3 * PA;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) pl_split_store(As, PA, arow + (NTHR / 8) * p, kg, ra[p]);
+    for (int p = 0; p < AP; ++p) pl_split_store_at(As + st_a + (NTHR / 8) * p * 64, PA, ra[p]);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + pl * PB + pl_off(brow + (NTHR / 4) * q, bc)) = rb[pl * BPP + q];
+      for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + st_b + (pl * PB + (NTHR / 4) * q * 64)) = rb[pl * BPP + q];
+  };
+
+  if (!setup(v)) return;
+  if (it.ke > it.kb) load();
+  while (true) {
+    const int ke = it.ke, cur_mt = mt, cur_nt = nt, cur_pslot = it.pslot;
+    int kt = it.kb;
+    f32x16 acc[TM][TN];
+    zero_acc<TM, TN>(acc);
+
+    if (ke > kt) {
+      if constexpr (NBUF == 2) {
+        store(0);
+        if (kt + 1 < ke) load();
+        __syncthreads();
+        while (true) {
+          mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
+          if (kt + 1 < ke) store(1);
+          if (kt + 2 < ke) load();
+          __syncthreads();
+          if (++kt >= ke) break;
+          mma_stage_pl<BM, BN, WM, WN>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, fa, fb);
+          if (kt + 1 < ke) store(0);
+          if (kt + 2 < ke) load();
+          __syncthreads();
+          if (++kt >= ke) break;
+        }
+      } else {
+        for (; kt < ke; ++kt) {
+          __syncthreads();
+          store(0);
+          __syncthreads();
+          if (kt + 1 < ke) load();
+          mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
+        }
+      }
+    }
+
+    v += gridDim.x;
+    if (cur_pslot >= 0) {
+      store_partial<TM, TN, NTHR>(slab, cur_pslot, acc, tid);
+    } else {
+      // Forward read xs[frame n] = x[frame n + cls]: the gradient of row m goes to frame n + cls when that frame is inside
+      // the clip; rows whose target falls outside write the zero the far clip end needs (a bijection over dx).
+      dgrad_epilogue<BM, BN, WM, WN>(acc, smem, tid, dx, add_src, add_mask, g, cur_mt, cur_nt, Mc, stat, [&](int mrow) {
+        if (st == 1) return mrow;
+        const int n = mrow / HcWc;
+        const int rem = mrow - n * HcWc;
+        const int hc = rem / Wc;
+        return (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
+      });
+    }
+    // (the next work item is set up after the epilogue: the dgrad epilogue needs the registers)
+    if (v >= total || !setup(v)) break;   // stride 2: total == gridDim.x, a single work item per workgroup
+    if (it.ke > it.kb) load();
+    __syncthreads();
+  }
+}
+
+// ---- wgrad, "P" family ---------------------------------------------------------------------------
+// dw tile BM (output channels) x BN (input channels of one filter tap), contraction over output pixels in steps of 32.
+// Both operands arrive with the contraction index as the ROW index (a pixel's channels are contiguous), i.e. transposed
+// with respect to what an MFMA operand fragment wants (8 consecutive k of one channel).  The planes are therefore kept in
+// LDS as they arrive, [32 pixels][channels] bf16 with a pitch of 2 * channels + 64 bytes, and the fragments are fetched with
+// ds_read_b64_tr_b16 (a 4 x 16 block read column-major per 16 lanes: two of them give a lane its 8 k-values).  With the
+// 64-byte skew the four rows of a block fall on distinct banks: reads and the 8-byte piece stores are conflict-free.
+// Eight waves (2 x 4), one workgroup per CU, one LDS stage.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+template <int COLS>
+__device__ __forceinline__ void pl_store_rows(unsigned char* __restrict__ base, int krow, int c4, const float4 v) {
+  constexpr int PITCH = 2 * COLS + 64, PLANE = 32 * PITCH;
+  const f32x4_t a = {v.x, v.y, v.z, v.w};
+  const bf16x4_t hi = __builtin_convertvector(a, bf16x4_t);
+  const f32x4_t r1 = a - __builtin_convertvector(hi, f32x4_t);
+  const bf16x4_t mid = __builtin_convertvector(r1, bf16x4_t);
+  const f32x4_t r2 = r1 - __builtin_convertvector(mid, f32x4_t);
+  const bf16x4_t lo = __builtin_convertvector(r2, bf16x4_t);
+  unsigned char* q = base + krow * PITCH + 8 * c4;
+  *reinterpret_cast<bf16x4_t*>(q) = hi;
+  *reinterpret_cast<bf16x4_t*>(q + PLANE) = mid;
+  *reinterpret_cast<bf16x4_t*>(q + 2 * PLANE) = lo;
+}
+
+// 8 k-values (pixels 16 s + 8 h .. + 7) of channel `cb + (lane & 31)` of plane image `p`
+template <int COLS>
+__device__ __forceinline__ bf16x8_t pl_frag_tr(const unsigned char* __restrict__ plane, int cb, int s, int lane) {
+  constexpr int PITCH = 2 * COLS + 64;
+  const int h = lane >> 5, q = (lane & 15) >> 2;
+  const unsigned char* a = plane + (16 * s + 8 * h + q) * PITCH + 2 * (cb + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+  typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+  const s16x4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a));
+  const s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 4 * PITCH));
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  const s16x8_t f = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8_t, f);
+}
+
+template <int BM, int BN, bool INCR>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_pl_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                float* __restrict__ slab, Geom g, int MTw, int NTw,
+                                                                int kt_per_split) {
+  constexpr int WM = 2, WN = 4, NTHR = 512;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AV = BM / 4, BV = BN / 4;
+  constexpr int AP = 32 * AV / NTHR, BP = 32 * BV / NTHR;
+  constexpr int PITCH_A = 2 * BM + 64, PITCH_B = 2 * BN + 64;
+  constexpr int PLANE_A = 32 * PITCH_A, PLANE_B = 32 * PITCH_B;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_b[3 * (PLANE_A + PLANE_B)];
+  unsigned char* const As = smem_b;
+  unsigned char* const Bs = smem_b + 3 * PLANE_A;
+
+  // slice-major, XCD-contiguous work order: all tiles of one K slice read the same rows of dy and x (see conv_wgrad_kernel)
+  const int tiles = MTw * NTw;
+  const int wi = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = wi / tiles;
+  const int tile = wi - split * tiles;
+  const int mt = tile % MTw, nt = tile / MTw;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int HoWo = g.Ho * g.Wo;
+  const int frame_bytes = g.H * g.W * g.Cin * 4;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * frame_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.M * g.Cout * 4, 0x00020000);
+
+  // A: dy rows m0 + krow, columns mt*BM + 4*c4
+  int a_off[AP], a_krow[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int idx = tid + NTHR * p;
+    a_krow[p] = idx / AV;
+    a_off[p] = (a_krow[p] * g.Cout + mt * BM + 4 * (idx % AV)) * 4;
+  }
+  // B: column tile -> (tap, ci block); rows = input pixels of the tap
+  const int per_tap = g.Cin / BN;
+  const int tap = nt / per_tap;
+  const int ci0 = (nt - tap * per_tap) * BN;
+  const int b_r = tap / g.S - g.pad, b_s = tap % g.S - g.pad;
+  int b_krow[BP], b_off[BP], b_cls[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) {
+    const int idx = tid + NTHR * p;
+    b_krow[p] = idx / BV;
+    const int ci = ci0 + 4 * (idx % BV);
+    b_cls[p] = shift_class(ci, g.fold);
+    b_off[p] = ((b_r * g.W + b_s) * g.Cin + ci) * 4 + b_cls[p] * frame_bytes;
+  }
+
+  const int kt_begin = split * kt_per_split;
+  const int nkt_all = (g.M + BK - 1) / BK;
+  const int kt_end = min(kt_begin + kt_per_split, nkt_all);
+
+  // incremental pixel state per B row (see conv_wgrad_kernel): no division in the loop
+  const int st = g.stride;
+  const int d_ho = BK / g.Wo, d_wo = BK - d_ho * g.Wo;
+  const int wrap_w = g.Wo * st, wrap_h = g.Ho * st;
+  const int px = g.Cin * 4;
+  const int inc0 = (d_ho * st * g.W + d_wo * st) * px;
+  const int inc1 = (st * g.W - wrap_w) * px;
+  const int inc2 = (g.H * g.W - wrap_h * g.W) * px;
+  int s_hi[BP], s_wi[BP], s_t[BP], s_off[BP];
+  if (INCR) {
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+      const int m = split * kt_per_split * BK + b_krow[p];
+      const int n = m / HoWo;
+      const int rem = m - n * HoWo;
+      const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+      s_hi[p] = ho * st;
+      s_wi[p] = wo * st;
+      s_t[p] = n % g.T;
+      s_off[p] = ((n * g.H + s_hi[p]) * g.W + s_wi[p]) * px + b_off[p];
+    }
+  }
+
+  float4 ra[AP], rb[BP];
+  auto load = [&](int kt) {
+    const int m0 = kt * BK;
+#pragma unroll
+    for (int p = 0; p < AP; ++p)  // rows past M lie past num_records: zeros
+      ra[p] = buf_load16(yr, a_off[p] + m0 * g.Cout * 4, 0);
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+      const int m = m0 + b_krow[p];
+      const bool mok = m < g.M;
+      int hi, wi_, t, off;
+      if (INCR) {
+        hi = s_hi[p];
+        wi_ = s_wi[p];
+        t = s_t[p];
+        off = s_off[p];
+        const int w2 = wi_ + d_wo * st;
+        const bool c1 = w2 >= wrap_w;
+        s_wi[p] = c1 ? w2 - wrap_w : w2;
+        const int h2 = hi + d_ho * st + (c1 ? st : 0);
+        const bool c2 = h2 >= wrap_h;
+        s_hi[p] = c2 ? h2 - wrap_h : h2;
+        const int t2 = t + (c2 ? 1 : 0);
+        s_t[p] = t2 == g.T ? 0 : t2;
+        s_off[p] = off + inc0 + (c1 ? inc1 : 0) + (c2 ? inc2 : 0);
+      } else {
+        const int mm = mok ? m : 0;
+        const int n = mm / HoWo;
+        const int rem = mm - n * HoWo;
+        const int ho = rem / g.Wo;
+        hi = ho * st;
+        wi_ = (rem - ho * g.Wo) * st;
+        t = n % g.T;
+        off = ((n * g.H + hi) * g.W + wi_) * px + b_off[p];
+      }
+      const bool v = mok && (unsigned)(hi + b_r) < (unsigned)g.H && (unsigned)(wi_ + b_s) < (unsigned)g.W &&
+                     (unsigned)(t + b_cls[p]) < (unsigned)g.T;
+      rb[p] = buf_load16(xr, off | (v ? 0 : kOOB), 0);
+    }
   };
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
 
-  if (it.ke > it.kb) {
-    if constexpr (NBUF == 2) {
-      int kt = it.kb;
-      load();
-      store(0);
-      if (kt + 1 < it.ke) load();
+  if (kt_begin < kt_end) {
+    load(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
       __syncthreads();
-      while (true) {
-        mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, wm, wn, lane);
-        if (kt + 1 < it.ke) store(1);
-        if (kt + 2 < it.ke) load();
-        __syncthreads();
-        if (++kt >= it.ke) break;
-        mma_stage_pl<BM, BN, WM, WN>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, wm, wn, lane);
-        if (kt + 1 < it.ke) store(0);
-        if (kt + 2 < it.ke) load();
-        __syncthreads();
-        if (++kt >= it.ke) break;
-      }
-    } else {
-      load();
-      for (int kt = it.kb; kt < it.ke; ++kt) {
-        __syncthreads();
-        store(0);
-        __syncthreads();
-        if (kt + 1 < it.ke) load();
-        mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, wm, wn, lane);
+#pragma unroll
+      for (int p = 0; p < AP; ++p) pl_store_rows<BM>(As, a_krow[p], (tid + NTHR * p) % AV, ra[p]);
+#pragma unroll
+      for (int p = 0; p < BP; ++p) pl_store_rows<BN>(Bs, b_krow[p], (tid + NTHR * p) % BV, rb[p]);
+      __syncthreads();
+      if (kt + 1 < kt_end) load(kt + 1);
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        bf16x8_t a[3][TM], b[3][TN];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[p][i] = pl_frag_tr<BM>(As + p * PLANE_A, 32 * WM * i + 32 * wm, s, lane);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[p][j] = pl_frag_tr<BN>(Bs + p * PLANE_B, 32 * WN * j + 32 * wn, s, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+          }
       }
     }
   }
-  if (it.pslot >= 0) {
-    store_partial<TM, TN, NTHR>(slab, it.pslot, acc, tid);
-    return;
+
+  float* out = slab + (size_t)split * g.Cout * g.Ktot;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = tap * g.Cin + ci0 + 32 * WN * j + 32 * wn + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = mt * BM + 32 * WM * i + 32 * wm + acc_row(e, lane);
+        out[(size_t)row * g.Ktot + col] = acc[i][j][e];
+      }
   }
-  dgrad_epilogue<BM, BN, WM, WN>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
-    if (st == 1) return mrow;
-    const int n = mrow / HcWc;
-    const int rem = mrow - n * HcWc;
-    const int hc = rem / Wc;
-    return (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
-  });
 }
 
 // ---- host side --------------------------------------------------------------------------------
@@ -2270,7 +2545,12 @@ int pl_tile_override() {
 }
 
 // M = GEMM rows, ncols = GEMM columns (Cout for fprop, Cin for dgrad), nk = 32-deep K-steps; ksplit_ok: stride-1 launches only
-PlPlan plan_pl(int M, int ncols, int nk, size_t ws_bytes, bool ksplit_ok) {
+bool pl_allow_256sq() {
+  static const bool on = getenv("BDVCIL_PL_256") == nullptr || atoi(getenv("BDVCIL_PL_256")) != 0;
+  return on;
+}
+
+PlPlan plan_pl(int M, int ncols, int nk, size_t ws_bytes, bool ksplit_ok, bool allow_256sq = true) {
   PlPlan best;
   best.cfg = -1;
   best.est_us = 1e30;
@@ -2278,6 +2558,7 @@ PlPlan plan_pl(int M, int ncols, int nk, size_t ws_bytes, bool ksplit_ok) {
   for (int c = 0; c < 3; ++c) {
     const PlCfg& k = kPlCfg[c];
     if (ncols % k.BN != 0) continue;
+    if (c == 2 && forced != 2 && !(allow_256sq && pl_allow_256sq())) continue;
     if (ncols % 256 == 0 && c == 1 && forced != 1) continue;  // 256-wide outputs: the activation tile is then split once per 256 columns
     if (forced >= 0 && forced != c && ncols % kPlCfg[forced].BN == 0) continue;
     PlPlan p;
@@ -2301,8 +2582,8 @@ PlPlan plan_pl(int M, int ncols, int nk, size_t ws_bytes, bool ksplit_ok) {
 
 // The tile configuration (hence the row count of the fused-statistics partials) must not depend on the caller's workspace:
 // it is chosen for the full split budget, and only the K-split is re-planned for the workspace actually passed.
-PlPlan plan_pl_ws(int M, int ncols, int nk, size_t ws_bytes, bool ksplit_ok) {
-  PlPlan p = plan_pl(M, ncols, nk, kMaxSplitWorkspace, ksplit_ok);
+PlPlan plan_pl_ws(int M, int ncols, int nk, size_t ws_bytes, bool ksplit_ok, bool allow_256sq = true) {
+  PlPlan p = plan_pl(M, ncols, nk, kMaxSplitWorkspace, ksplit_ok, allow_256sq);
   if (p.cfg >= 0 && ksplit_ok && ws_bytes < kMaxSplitWorkspace)
     p.wk = plan_work_pl(p.MT * p.NT, nk, kPlCfg[p.cfg].iter_us, p.seg_bytes, ws_bytes, &p.est_us);
   return p;
@@ -2354,6 +2635,46 @@ WgradPlan plan_wgrad(const bdv_conv_geom* g) {
   return p;
 }
 
+bool pl_wgrad_ok(const bdv_conv_geom* g) { return g->Cin % 128 == 0 && g->Cout % 128 == 0; }
+
+// wgrad of the P family: one workgroup per CU, tiles of 128 / 256 output channels x 128 / 256 input channels of a tap
+struct WgradPlPlan {
+  int BM, BN, MTw, NTw, splits, kt_per_split;
+};
+
+WgradPlPlan plan_wgrad_pl(const bdv_conv_geom* g) {
+  WgradPlPlan p;
+  p.BM = g->Cout % 256 == 0 ? 256 : 128;
+  p.BN = g->Cin % 256 == 0 ? 256 : 128;
+  p.MTw = g->Cout / p.BM;
+  p.NTw = g->R * g->S * (g->Cin / p.BN);
+  const int64_t M = (int64_t)g->N * g->Ho * g->Wo;
+  const int nkt = (int)((M + BK - 1) / BK);
+  const int tiles = p.MTw * p.NTw;
+  const int W = 256;
+  const double t_iter = 2.7 * (double)(p.BM * p.BN) / (128.0 * 256.0);
+  const double dw_bytes = (double)g->Cout * g->R * g->S * g->Cin * 4.0;
+  int best_s = 1;
+  double best_cost = 1e30;
+  for (int k = 1; k <= 6; ++k) {  // k rounds of 256 blocks
+    int sp = (int)(((long long)k * W) / tiles);
+    if (sp < 1) sp = 1;
+    if (sp > 1024) sp = 1024;
+    while (sp > 1 && (nkt + sp - 1) / sp < 4) --sp;
+    const int per = (nkt + sp - 1) / sp;
+    const double rounds = (double)(((long long)tiles * sp + W - 1) / W);
+    const double cost = rounds * per * t_iter + 4.0 + 2.0 * sp * dw_bytes / 4.0e6;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best_s = sp;
+    }
+  }
+  const int per = (nkt + best_s - 1) / best_s;
+  p.kt_per_split = per;
+  p.splits = (nkt + per - 1) / per;
+  return p;
+}
+
 }  // namespace
 
 extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
@@ -2381,7 +2702,7 @@ extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
     const size_t n2 = q.wk.split > 1 ? (size_t)q.wk.rem_tiles * q.wk.split * q.seg_bytes : 0;
     need = n2 > need ? n2 : need;
   } else if (kind == 1 && pl_dgrad_ok(gg) && gg->stride == 1) {
-    const PlPlan q = plan_pl(g.M, g.Cin, g.Ktot / BK, kMaxSplitWorkspace, true);
+    const PlPlan q = plan_pl(g.M, g.Cin, g.Ktot / BK, kMaxSplitWorkspace, true, false);
     const size_t n2 = q.wk.split > 1 ? (size_t)q.wk.rem_tiles * q.wk.split * q.seg_bytes : 0;
     need = n2 > need ? n2 : need;
   }
@@ -2557,7 +2878,7 @@ extern "C" int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* gg) {
 extern "C" int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* gg) {
   if (check_geom(gg, "bdv_conv_dgrad_pl_stat_rows")) return 0;
   if (!pl_dgrad_ok(gg) || gg->stride != 1) return bdv_conv_dgrad_stat_rows(gg);
-  const PlPlan p = plan_pl(gg->N * gg->H * gg->W, gg->Cin, gg->R * gg->S * gg->Cout / BK, kMaxSplitWorkspace, true);
+  const PlPlan p = plan_pl(gg->N * gg->H * gg->W, gg->Cin, gg->R * gg->S * gg->Cout / BK, kMaxSplitWorkspace, true, false);
   return p.cfg >= 0 ? p.MT : 0;
 }
 
@@ -2610,7 +2931,7 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
             g.W, g.Cin, g.Cout, g.R, g.stride, p.cfg, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split, p.est_us);
 #define BDV_FPROP_PL(BM_, BN_, WM_, WN_, NB_)                                                                                         \
   do {                                                                                                                                \
-    hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y, g, p.NT,   \
+    hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_>), dim3(blocks < 256 ? blocks : 256), dim3(64 * WM_ * WN_), 0, s, x, wp, y, g, p.NT,   \
                        p.wk, slab, epi);                                                                                              \
     BDV_LAUNCH_CHECK("bdv_conv_fprop_pl");                                                                                            \
     if (p.wk.split > 1) {                                                                                                             \
@@ -2656,13 +2977,15 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
   hipStream_t s = (hipStream_t)stream;
   const int st = g.stride;
   const int Mc0 = g.N * ((g.H + st - 1) / st) * ((g.W + st - 1) / st);  // largest parity class
+  // (256 x 256 tiles only when forced: the dgrad epilogue does not fit the register file next to 128 accumulator registers)
   PlPlan p = plan_pl_ws(st == 1 ? g.M : Mc0, g.Cin, g.Ktot / BK,
-                        workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, st == 1);
+                        workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, st == 1, false);
   BDV_REQUIRE(p.cfg >= 0, "bdv_conv_dgrad_pl: no tile configuration for Cin=%d", g.Cin);
   if (st != 1) p.wk.dp_tiles = ((p.MT + 7) / 8) * 8 * p.NT;  // padded grid per parity class
   // the statistics partial has one row per row tile of THIS kernel
   stat.MT = p.MT;
-  const dim3 grid(p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split, st * st);
+  const int work_items = p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split;
+  const dim3 grid(st == 1 && work_items > 256 ? 256 : work_items, st * st);  // stride 1: persistent workgroups, one per CU
   float* slab = (float*)workspace;
   const unsigned short* dp = (const unsigned short*)planes_dgrad;
   if (debug_plan())
@@ -2774,6 +3097,53 @@ extern "C" int bdv_conv_wgrad_partial_x3(const float* dy, const float* x, const 
   BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(slab), "bdv_conv_wgrad_partial_x3: pointers must be 16-byte aligned");
   int splits = 0;
   return wgrad_partial("bdv_conv_wgrad_partial_x3", dy, x, gg, slab, slab_bytes, (hipStream_t)stream, &splits, true);
+}
+
+extern "C" int bdv_conv_wgrad_pl_splits(const bdv_conv_geom* gg) {
+  if (check_geom(gg, "bdv_conv_wgrad_pl_splits")) return 0;
+  return pl_wgrad_ok(gg) ? plan_wgrad_pl(gg).splits : plan_wgrad(gg).splits;
+}
+
+extern "C" int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const bdv_conv_geom* gg, void* slab, size_t slab_bytes,
+                                         void* stream) {
+  if (int e = check_geom(gg, "bdv_conv_wgrad_partial_pl")) return e;
+  BDV_REQUIRE(dy && x && slab, "bdv_conv_wgrad_partial_pl: null pointer");
+  BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(slab), "bdv_conv_wgrad_partial_pl: pointers must be 16-byte aligned");
+  if (!pl_wgrad_ok(gg)) {
+    int splits = 0;
+    return wgrad_partial("bdv_conv_wgrad_partial_pl", dy, x, gg, slab, slab_bytes, (hipStream_t)stream, &splits, true);
+  }
+  const WgradPlPlan p = plan_wgrad_pl(gg);
+  const size_t need = (size_t)p.splits * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(float);
+  if (slab_bytes < need) {
+    bdv_set_error("bdv_conv_wgrad_partial_pl: slab %zu < required %zu bytes", slab_bytes, need);
+    return BDV_EWORKSPACE;
+  }
+  Geom g = make_geom(gg);
+  g.M = g.N * g.Ho * g.Wo;
+  g.Ktot = g.R * g.S * g.Cin;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(p.MTw * p.NTw * p.splits);
+  if (debug_plan())
+    fprintf(stderr, "[bdv plan] wgrad_pl %dx%d Cin %d Cout %d k%d s%d: %dx%d tiles %d -> splits %d x %d k-iters\n", gg->H, gg->W, gg->Cin,
+            gg->Cout, gg->R, gg->stride, p.BM, p.BN, p.MTw * p.NTw, p.splits, p.kt_per_split);
+  const bool incr = g.Ho * g.Wo > BK && BK / g.Wo + 1 <= g.Ho;
+#define BDV_WGRAD_PL(BM_, BN_)                                                                                                   \
+  do {                                                                                                                           \
+    if (incr)                                                                                                                    \
+      hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, true>), grid, dim3(512), 0, s, dy, x, (float*)slab, g, p.MTw, p.NTw,      \
+                         p.kt_per_split);                                                                                        \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, false>), grid, dim3(512), 0, s, dy, x, (float*)slab, g, p.MTw, p.NTw,     \
+                         p.kt_per_split);                                                                                        \
+  } while (0)
+  if (p.BM == 256 && p.BN == 256) BDV_WGRAD_PL(256, 256);
+  else if (p.BM == 256) BDV_WGRAD_PL(256, 128);
+  else if (p.BN == 256) BDV_WGRAD_PL(128, 256);
+  else BDV_WGRAD_PL(128, 128);
+#undef BDV_WGRAD_PL
+  BDV_LAUNCH_CHECK("bdv_conv_wgrad_partial_pl");
+  return BDV_OK;
 }
 
 extern "C" int bdv_wgrad_reduce_batched(const float* const* slabs, float* const* dws, const int* splits, const int64_t* numels,

@@ -101,6 +101,7 @@ import weakref as _weakref
 WEIGHT_EPOCH = 0
 _PLANES = {}        # id(base tensor) -> [weakref, (data_ptr, version, epoch), uint8 buffer holding both layouts]
 USE_PL = _os.environ.get('BDVCIL_PL', '1') != '0'       # 0: the round-1 bf16-piece kernels (operands split in the K loop)
+USE_PL_WGRAD = _os.environ.get('BDVCIL_PL_WGRAD', '1') != '0'
 
 
 def bump_weight_epoch():
@@ -516,11 +517,13 @@ def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, x3: Optio
     ``wgrad_reduce_batched`` (the slab must stay alive until then)."""
     _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
     _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
-    splits = lib().bdv_conv_wgrad_splits(ctypes.byref(g))
+    use_x3 = WGRAD_X3 if x3 is None else x3
+    use_pl = use_x3 and USE_PL_WGRAD
+    splits = (lib().bdv_conv_wgrad_pl_splits if use_pl else lib().bdv_conv_wgrad_splits)(ctypes.byref(g))
     if splits <= 0:
         check(-1, 'bdv_conv_wgrad_splits')
     slab = torch.empty((splits, g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
-    fn = lib().bdv_conv_wgrad_partial_x3 if (WGRAD_X3 if x3 is None else x3) else lib().bdv_conv_wgrad_partial
+    fn = lib().bdv_conv_wgrad_partial_pl if use_pl else lib().bdv_conv_wgrad_partial_x3 if use_x3 else lib().bdv_conv_wgrad_partial
     check(fn(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, _stream()), 'bdv_conv_wgrad_partial')
     if dw is None:
         dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)

@@ -147,6 +147,13 @@ int bdv_conv_wgrad_partial(const float* dy, const float* x, const bdv_conv_geom*
                            void* stream);
 int bdv_wgrad_reduce_batched(const float* const* slabs, float* const* dws, const int* splits, const int64_t* numels, int n,
                              float beta, void* stream);
+/* The weight gradient's main kernel of the default arithmetic for Cout and Cin multiples of 128 (other shapes run the kernels of
+ * bdv_conv_wgrad_partial): 8 waves per workgroup, tiles of 128 / 256 output channels x 128 / 256 input channels of one tap,
+ * both operand tiles split into bf16 pieces in the loader and read from LDS with ds_read_b64_tr_b16.  The slab holds
+ * bdv_conv_wgrad_pl_splits(g) partial products of dw's size; reduce with bdv_wgrad_reduce_batched. */
+int bdv_conv_wgrad_pl_splits(const bdv_conv_geom* g);
+int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const bdv_conv_geom* g, void* slab, size_t slab_bytes,
+                              void* stream);
 /* EXPERIMENTAL counterpart of bdv_conv_fprop_x3 for the weight gradient's main kernel (128x128 tiles, i.e. Cout and Cin
  * multiples of 128; other shapes run the fp32-MFMA kernels).  Same slab layout and split count as bdv_conv_wgrad_partial. */
 int bdv_conv_wgrad_partial_x3(const float* dy, const float* x, const bdv_conv_geom* g, void* slab, size_t slab_bytes,

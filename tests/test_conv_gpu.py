@@ -340,12 +340,13 @@ def test_plane_kernels_every_tile(case, tile, dev):
     N, H, W, Cin, Cout, R, st, pad, T, fold = case
     x, w = _mk(case, 21)
     x.requires_grad_(True)
+    w.requires_grad_(True)
     y = _ref(x, w, st, pad, T, fold)
     dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(22))
     y.backward(dy)
     g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad, T, fold)
     xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev)
-    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.detach().permute(0, 2, 3, 1).contiguous().to(dev)
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev)
     check(lib().bdv_conv_debug_force_tile(tile), 'force_tile')
     try:
@@ -368,6 +369,10 @@ def test_plane_kernels_every_tile(case, tile, dev):
         d1 = K.conv_dgrad(dyd, wd, g, add_src=add.to(dev), add_mask_src=bits, x3=False)
         _close(d3.cpu(), want)
         _close(d3, d1, tol=4e-6)
+        dw3 = K.conv_wgrad(dyd, xd, g, x3=True)               # 8-wave weight-gradient kernel (transposed LDS reads)
+        _close(dw3.cpu(), w.grad.permute(0, 2, 3, 1))
+        _close(dw3, K.conv_wgrad(dyd, xd, g, x3=False), tol=4e-6)
+        assert torch.equal(K.conv_wgrad(dyd, xd, g, x3=True), dw3)
         if st == 1:          # BatchNorm-backward statistics of the tensor dx feeds, taken in the epilogue
             yprev = torch.randn(N, H, W, Cin, generator=gen).to(dev)
             gamma = (torch.rand(Cin, generator=gen) + 0.5).to(dev)

@@ -1,0 +1,16 @@
+# conv-only GPU call: kernel tests, then the per-site table under a few planner settings
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+step() {  # name, limit, command...
+  local name=$1 limit=$2; shift 2
+  timeout -k 10 $limit "$@" > gpurun_out/$name.log 2>&1
+  local rc=$?
+  echo "[$name] rc=$rc"
+  tail -n 4 gpurun_out/$name.log
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$name] killed at its limit: stopping"; exit $rc; fi
+}
+step pytest_conv 900 python -m pytest tests/test_conv_gpu.py tests/test_conv_sites_gpu.py tests/test_ops_gpu.py -m gpu -q -x
+step bench_conv_pl 200 python tools/bench_conv.py
+BDVCIL_PL_256=0 step bench_conv_pl_no256 200 python tools/bench_conv.py
+BDVCIL_PL_WGRAD=0 BDVCIL_DEBUG_PLAN=1 step bench_conv_plan 200 python tools/bench_conv.py
+step bench 400 python bench.py --steps 12 --warmup 4 --no-cpu-baseline
