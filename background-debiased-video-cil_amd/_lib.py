@@ -55,6 +55,7 @@ SIGNATURES = {
     'bdv_conv_weight_planes_bytes': (c_size_t, [POINTER(ConvGeom)]),
     'bdv_conv_split_weights': (c_int, [P, POINTER(ConvGeom), P, P, P]),
     'bdv_conv_debug_force_tile': (c_int, [c_int]),
+    'bdv_conv_uses_planes': (c_int, [POINTER(ConvGeom), c_int]),
     'bdv_conv_fprop_pl_stat_rows': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_dgrad_pl_stat_rows': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_fprop_pl': (c_int, [P, P, P, P, POINTER(ConvGeom), P, POINTER(ConvAffine), P, c_size_t, P]),

@@ -1809,62 +1809,54 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
   constexpr int NTHR = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM * 8 / NTHR;    // float4 loads of the activation tile per thread and K-step
-  constexpr int BPP = BN * 4 / NTHR;   // 16-byte loads per weight plane per thread and K-step
+  constexpr int BPP = (BN * 4 + NTHR - 1) / NTHR;   // 16-byte loads per weight plane per thread and K-step
   constexpr int PA = BM * 64, PB = BN * 64, STAGE = 3 * (PA + PB);
-  static_assert(AP >= 1 && BPP >= 1 && NBUF * STAGE >= WM * 32 * BN * 4, "tile / epilogue staging do not fit");
+  static_assert(AP >= 1 && NBUF * STAGE >= WM * 32 * BN * 4, "tile / epilogue staging do not fit");
   __shared__ __attribute__((aligned(16))) unsigned char smem_b[NBUF * STAGE];
   float* const smem = reinterpret_cast<float*>(smem_b);
 
   const int nk = g.Ktot / BK;
+  const WorkItem it = get_work(blockIdx.x, wk, nk);
+  const int mt = it.tile / NT, nt = it.tile - mt * NT;
+
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int arow = tid >> 3, kg = tid & 7;
   const int brow = tid >> 2, bc = tid & 3;
   const int HoWo = g.Ho * g.Wo;
-  const int RS = g.R * g.S;
   const int frame_bytes = g.H * g.W * g.Cin * 4;
   const int plane_bytes = g.Cout * g.Ktot * 2;
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * frame_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 3 * plane_bytes, 0x00020000);
 
-  // The workgroup is persistent: it walks the work items v = blockIdx.x, + gridDim.x, ... (one workgroup per CU, so a short
-  // K loop cannot hide its prologue and its epilogue behind another workgroup's MFMAs; instead the first loads of the next
-  // tile are issued before the epilogue of the current one, and the epilogue's stores drain while the next tile computes).
-  const int total = wk.dp_tiles + wk.rem_tiles * wk.split;
-  int v = blockIdx.x;
-  if (v >= total) return;
-
-  WorkItem it;
-  int mt, nt;
   int a_base[AP], a_t[AP], a_hi0[AP], a_wi0[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int m = mt * BM + arow + (NTHR / 8) * p;
+    const bool ok = m < g.M;
+    int n, rem, ho, wo;
+    fast_divmod(ok ? m : 0, HoWo, g.rcp_HoWo, n, rem);
+    fast_divmod(rem, g.Wo, g.rcp_Wo, ho, wo);
+    a_t[p] = n % g.T;
+    a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);  // rows past M fail every bounds test
+    a_wi0[p] = wo * g.stride - g.pad;
+    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad) * g.Cin * 4 + 16 * kg;
+  }
   int b_base[BPP];
-  int chunk, r, s, kt_w;   // K index state (uniform): K-step kt = chunk * R*S + r * S + s; the weight planes are stored in this order
-  auto setup = [&](int vv) {
-    it = get_work(vv, wk, nk);
-    mt = it.tile / NT;
-    nt = it.tile - mt * NT;
+  const bool b_active = BN * 4 >= NTHR || tid < BN * 4;   // a 64-row weight tile is loaded by the first four waves only
 #pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      const int m = mt * BM + arow + (NTHR / 8) * p;
-      const bool ok = m < g.M;
-      int n, rem, ho, wo;
-      fast_divmod(ok ? m : 0, HoWo, g.rcp_HoWo, n, rem);
-      fast_divmod(rem, g.Wo, g.rcp_Wo, ho, wo);
-      a_t[p] = n % g.T;
-      a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);  // rows past M fail every bounds test
-      a_wi0[p] = wo * g.stride - g.pad;
-      a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad) * g.Cin * 4 + 16 * kg;
-    }
-#pragma unroll
-    for (int q = 0; q < BPP; ++q) b_base[q] = (nt * BN + brow + (NTHR / 4) * q) * 64 + 16 * bc;
-    chunk = it.kb / RS;
+  for (int q = 0; q < BPP; ++q) b_base[q] = b_active ? (nt * BN + brow + (NTHR / 4) * q) * 64 + 16 * bc : kOOB;
+
+  // K index state (uniform): K-step kt = chunk * R*S + r * S + s; the weight planes are stored in this order
+  const int RS = g.R * g.S;
+  int chunk = it.kb / RS, r, s, kt_w = it.kb;
+  {
     const int tap = it.kb - chunk * RS;
     r = tap / g.S;
     s = tap - r * g.S;
-    kt_w = it.kb;
-  };
+  }
 
   float4 ra[AP];
   u32x4 rb[3 * BPP];
@@ -1874,9 +1866,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
     const int koff_b = kt_w * g.Cout * 64;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const bool ok = (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W &&
-                      (unsigned)(a_t[p] + cls) < (unsigned)g.T;
-      ra[p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (ok ? 0 : kOOB), 0);
+      const bool v = (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W &&
+                     (unsigned)(a_t[p] + cls) < (unsigned)g.T;
+      ra[p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB), 0);
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
@@ -1900,64 +1892,50 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
     unsigned char* const Bs = As + 3 * PA;
 #pragma unroll
     for (int p = 0; p < AP; ++p) pl_split_store_at(As + st_a + (NTHR / 8) * p * 64, PA, ra[p]);
+    if (b_active) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + st_b + (pl * PB + (NTHR / 4) * q * 64)) = rb[pl * BPP + q];
+        for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + st_b + (pl * PB + (NTHR / 4) * q * 64)) = rb[pl * BPP + q];
+    }
   };
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
 
-  setup(v);
-  load();
-  while (true) {
-    const int ke = it.ke, cur_mt = mt, cur_nt = nt, cur_pslot = it.pslot;
+  if constexpr (NBUF == 2) {
     int kt = it.kb;
-    f32x16 acc[TM][TN];
-    zero_acc<TM, TN>(acc);
-
-    if constexpr (NBUF == 2) {
-      store(0);
-      if (kt + 1 < ke) load();
+    load();
+    store(0);
+    if (kt + 1 < it.ke) load();
+    __syncthreads();
+    while (true) {
+      mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
+      if (kt + 1 < it.ke) store(1);
+      if (kt + 2 < it.ke) load();
       __syncthreads();
-      while (true) {
-        mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
-        if (kt + 1 < ke) store(1);
-        if (kt + 2 < ke) load();
-        __syncthreads();
-        if (++kt >= ke) break;
-        mma_stage_pl<BM, BN, WM, WN>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, fa, fb);
-        if (kt + 1 < ke) store(0);
-        if (kt + 2 < ke) load();
-        __syncthreads();
-        if (++kt >= ke) break;
-      }
-    } else {
-      for (; kt < ke; ++kt) {
-        __syncthreads();
-        store(0);
-        __syncthreads();
-        if (kt + 1 < ke) load();
-        mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
-      }
+      if (++kt >= it.ke) break;
+      mma_stage_pl<BM, BN, WM, WN>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, fa, fb);
+      if (kt + 1 < it.ke) store(0);
+      if (kt + 2 < it.ke) load();
+      __syncthreads();
+      if (++kt >= it.ke) break;
     }
-
-    v += gridDim.x;
-    const bool more = v < total;
-    constexpr bool EARLY = TM * TN <= 4;   // register budget: not with 128 accumulator registers
-    if (EARLY && more) {  // first loads of the next work item: in flight during the epilogue
-      setup(v);
-      load();
+  } else {
+    load();
+    for (int kt = it.kb; kt < it.ke; ++kt) {
+      __syncthreads();
+      store(0);
+      __syncthreads();
+      if (kt + 1 < it.ke) load();
+      mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
     }
-    if (cur_pslot >= 0)
-      store_partial<TM, TN, NTHR>(slab, cur_pslot, acc, tid);
-    else
-      fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, cur_mt, cur_nt, tid);
-    if (!more) break;
-    if (!EARLY) {
-      setup(v);
-      load();
-    }
-    __syncthreads();  // the epilogue is done with the staging area before the next tile's stage stores
   }
+
+  if (it.pslot >= 0) {
+    store_partial<TM, TN, NTHR>(slab, it.pslot, acc, tid);
+    return;
+  }
+  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
 }
 
 // ---- dgrad ------------------------------------------------------------------------------------
@@ -1973,9 +1951,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
   constexpr int NTHR = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM * 8 / NTHR;
-  constexpr int BPP = BN * 4 / NTHR;
+  constexpr int BPP = (BN * 4 + NTHR - 1) / NTHR;
   constexpr int PA = BM * 64, PB = BN * 64, STAGE = 3 * (PA + PB);
-  static_assert(AP >= 1 && BPP >= 1 && NBUF * STAGE >= WM * 32 * BN * 4, "tile / epilogue staging do not fit");
+  static_assert(AP >= 1 && NBUF * STAGE >= WM * 32 * BN * 4, "tile / epilogue staging do not fit");
   __shared__ __attribute__((aligned(16))) unsigned char smem_b[NBUF * STAGE];
   float* const smem = reinterpret_cast<float*>(smem_b);
 
@@ -1992,6 +1970,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
   const int ntap = nr * ns;
   const int nk = ntap * g.Cout / BK;  // 0 for a class no filter tap reaches (e.g. 1x1 stride 2, odd pixels)
 
+  int mt, nt;
+  WorkItem it;
+  if (st == 1) {
+    it = get_work(blockIdx.x, wk, nk);
+    mt = it.tile / NT;
+    nt = it.tile - mt * NT;
+  } else {  // parity classes have different sizes: padded grid, no K split
+    const int id = blockIdx.x;
+    const int xcd = id & 7, jj = id >> 3;
+    mt = (jj / NT) * 8 + xcd;
+    nt = jj % NT;
+    if (mt >= MT) return;
+    it.tile = 0;
+    it.kb = 0;
+    it.ke = nk;
+    it.pslot = -1;
+  }
+
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -1999,57 +1995,36 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
   const int brow = tid >> 2, bc = tid & 3;
   const int HcWc = Hc * Wc;
   const int RS = g.R * g.S;
-  const int nchunk = g.Cout / BK;
   const int plane_bytes = g.Cout * RS * g.Cin * 2;
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.N * g.Ho * g.Wo * g.Cout * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)dp, 0, 3 * plane_bytes, 0x00020000);
 
-  // persistent over the work items of a stride-1 launch (see conv_fprop_pl_kernel); the parity classes of a stride-2 launch
-  // have different sizes and keep one (padded) grid entry per tile
-  const int total = st == 1 ? wk.dp_tiles + wk.rem_tiles * wk.split : (int)gridDim.x;
-  int v = blockIdx.x;
-  if (v >= total) return;
-
-  WorkItem it;
-  int mt, nt;
   int a_base[AP], a_h[AP], a_w[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int m = mt * BM + arow + (NTHR / 8) * p;
+    const bool ok = m < Mc;
+    const int mm = ok ? m : 0;
+    const int n = mm / HcWc;
+    const int rem = mm - n * HcWc;
+    const int hc = rem / Wc, wc = rem - hc * Wc;
+    a_h[p] = ok ? hc + bh : -(1 << 20);
+    a_w[p] = wc + bw;
+    a_base[p] = ((n * g.Ho + hc + bh) * g.Wo + wc + bw) * g.Cout * 4 + 16 * kg;
+  }
   int b_base[BPP];
-  int chunk, ir, is;  // K index state (uniform): kt = chunk * ntap + ir * ns + is  (tap-fastest)
-  auto setup = [&](int vv) -> bool {
-    if (st == 1) {
-      it = get_work(vv, wk, nk);
-      mt = it.tile / NT;
-      nt = it.tile - mt * NT;
-    } else {
-      const int xcd = vv & 7, jj = vv >> 3;
-      mt = (jj / NT) * 8 + xcd;
-      nt = jj % NT;
-      if (mt >= MT) return false;
-      it.tile = 0;
-      it.kb = 0;
-      it.ke = nk;
-      it.pslot = -1;
-    }
+  const bool b_active = BN * 4 >= NTHR || tid < BN * 4;   // a 64-row weight tile is loaded by the first four waves only
 #pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      const int m = mt * BM + arow + (NTHR / 8) * p;
-      const bool ok = m < Mc;
-      const int mm = ok ? m : 0;
-      const int n = mm / HcWc;
-      const int rem = mm - n * HcWc;
-      const int hc = rem / Wc, wc = rem - hc * Wc;
-      a_h[p] = ok ? hc + bh : -(1 << 20);
-      a_w[p] = wc + bw;
-      a_base[p] = ((n * g.Ho + hc + bh) * g.Wo + wc + bw) * g.Cout * 4 + 16 * kg;
-    }
-#pragma unroll
-    for (int q = 0; q < BPP; ++q) b_base[q] = (nt * BN + brow + (NTHR / 4) * q) * 64 + 16 * bc;
-    chunk = ntap > 0 ? it.kb / ntap : 0;
+  for (int q = 0; q < BPP; ++q) b_base[q] = b_active ? (nt * BN + brow + (NTHR / 4) * q) * 64 + 16 * bc : kOOB;
+
+  // K index state (uniform): kt = chunk * ntap + ir * ns + is  (tap-fastest)
+  int chunk = ntap > 0 ? it.kb / ntap : 0, ir, is;
+  {
     const int ct = ntap > 0 ? it.kb - chunk * ntap : 0;
     ir = ns > 0 ? ct / ns : 0;
     is = ct - ir * ns;
-    return true;
-  };
+  }
+  const int nchunk = g.Cout / BK;
 
   float4 ra[AP];
   u32x4 rb[3 * BPP];
@@ -2059,8 +2034,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
     const int koff_b = (tap * nchunk + chunk) * g.Cin * 64;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const bool ok = (unsigned)(a_h[p] - ir) < (unsigned)g.Ho && (unsigned)(a_w[p] - is) < (unsigned)g.Wo;
-      ra[p] = buf_load16(yr, (a_base[p] + koff_a) | (ok ? 0 : kOOB), 0);
+      const bool v = (unsigned)(a_h[p] - ir) < (unsigned)g.Ho && (unsigned)(a_w[p] - is) < (unsigned)g.Wo;
+      ra[p] = buf_load16(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB), 0);
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
@@ -2083,67 +2058,58 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
     unsigned char* const Bs = As + 3 * PA;
 #pragma unroll
     for (int p = 0; p < AP; ++p) pl_split_store_at(As + st_a + (NTHR / 8) * p * 64, PA, ra[p]);
+    if (b_active) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + st_b + (pl * PB + (NTHR / 4) * q * 64)) = rb[pl * BPP + q];
+        for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + st_b + (pl * PB + (NTHR / 4) * q * 64)) = rb[pl * BPP + q];
+    }
   };
 
-  if (!setup(v)) return;
-  if (it.ke > it.kb) load();
-  while (true) {
-    const int ke = it.ke, cur_mt = mt, cur_nt = nt, cur_pslot = it.pslot;
-    int kt = it.kb;
-    f32x16 acc[TM][TN];
-    zero_acc<TM, TN>(acc);
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
 
-    if (ke > kt) {
-      if constexpr (NBUF == 2) {
-        store(0);
-        if (kt + 1 < ke) load();
+  if (it.ke > it.kb) {
+    if constexpr (NBUF == 2) {
+      int kt = it.kb;
+      load();
+      store(0);
+      if (kt + 1 < it.ke) load();
+      __syncthreads();
+      while (true) {
+        mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
+        if (kt + 1 < it.ke) store(1);
+        if (kt + 2 < it.ke) load();
         __syncthreads();
-        while (true) {
-          mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
-          if (kt + 1 < ke) store(1);
-          if (kt + 2 < ke) load();
-          __syncthreads();
-          if (++kt >= ke) break;
-          mma_stage_pl<BM, BN, WM, WN>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, fa, fb);
-          if (kt + 1 < ke) store(0);
-          if (kt + 2 < ke) load();
-          __syncthreads();
-          if (++kt >= ke) break;
-        }
-      } else {
-        for (; kt < ke; ++kt) {
-          __syncthreads();
-          store(0);
-          __syncthreads();
-          if (kt + 1 < ke) load();
-          mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
-        }
+        if (++kt >= it.ke) break;
+        mma_stage_pl<BM, BN, WM, WN>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, fa, fb);
+        if (kt + 1 < it.ke) store(0);
+        if (kt + 2 < it.ke) load();
+        __syncthreads();
+        if (++kt >= it.ke) break;
+      }
+    } else {
+      load();
+      for (int kt = it.kb; kt < it.ke; ++kt) {
+        __syncthreads();
+        store(0);
+        __syncthreads();
+        if (kt + 1 < it.ke) load();
+        mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
       }
     }
-
-    v += gridDim.x;
-    if (cur_pslot >= 0) {
-      store_partial<TM, TN, NTHR>(slab, cur_pslot, acc, tid);
-    } else {
-      // Forward read xs[frame n] = x[frame n + cls]: the gradient of row m goes to frame n + cls when that frame is inside
-      // the clip; rows whose target falls outside write the zero the far clip end needs (a bijection over dx).
-      dgrad_epilogue<BM, BN, WM, WN>(acc, smem, tid, dx, add_src, add_mask, g, cur_mt, cur_nt, Mc, stat, [&](int mrow) {
-        if (st == 1) return mrow;
-        const int n = mrow / HcWc;
-        const int rem = mrow - n * HcWc;
-        const int hc = rem / Wc;
-        return (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
-      });
-    }
-    // (the next work item is set up after the epilogue: the dgrad epilogue needs the registers)
-    if (v >= total || !setup(v)) break;   // stride 2: total == gridDim.x, a single work item per workgroup
-    if (it.ke > it.kb) load();
-    __syncthreads();
   }
+  if (it.pslot >= 0) {
+    store_partial<TM, TN, NTHR>(slab, it.pslot, acc, tid);
+    return;
+  }
+  dgrad_epilogue<BM, BN, WM, WN>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
+    if (st == 1) return mrow;
+    const int n = mrow / HcWc;
+    const int rem = mrow - n * HcWc;
+    const int hc = rem / Wc;
+    return (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
+  });
 }
 
 // ---- wgrad, "P" family ---------------------------------------------------------------------------
@@ -2494,12 +2460,14 @@ FdPlan plan_dgrad(const Geom& g, size_t ws_bytes, bool x3 = false) {
 }
 
 // ---- planner of the "P" kernels (8 waves, ONE workgroup per CU: a round is 256 blocks) ----------------------------------
-// Tile configurations: 0 = 128 x 256 (two LDS stages), 1 = 256 x 128 (two stages), 2 = 256 x 256 (one stage).
+// Tile configurations: 0 = 128 x 256 (two LDS stages), 1 = 256 x 128 (two stages), 2 = 256 x 256 (one stage, opt-in),
+// 3 = 256 x 64 (two stages; the 64-channel layers).
 struct PlCfg {
   int BM, BN, nbuf;
   double iter_us;  // one 32-deep K-step of a block, measured per-CU rate (tools/ubench/gemm_x3p.hip: ~200 / ~230 TFLOP/s chip-wide)
 };
-constexpr PlCfg kPlCfg[3] = {{128, 256, 2, 2.7}, {256, 128, 2, 2.7}, {256, 256, 1, 4.7}};
+constexpr int kNumPlCfg = 4;
+constexpr PlCfg kPlCfg[kNumPlCfg] = {{128, 256, 2, 2.7}, {256, 128, 2, 2.7}, {256, 256, 1, 4.7}, {256, 64, 2, 1.9}};
 
 struct PlPlan {
   int cfg;  // -1: shape not covered by the P kernels
@@ -2545,52 +2513,66 @@ int pl_tile_override() {
 }
 
 // M = GEMM rows, ncols = GEMM columns (Cout for fprop, Cin for dgrad), nk = 32-deep K-steps; ksplit_ok: stride-1 launches only
-bool pl_allow_256sq() {
-  static const bool on = getenv("BDVCIL_PL_256") == nullptr || atoi(getenv("BDVCIL_PL_256")) != 0;
-  return on;
-}
-
-PlPlan plan_pl(int M, int ncols, int nk, size_t ws_bytes, bool ksplit_ok, bool allow_256sq = true) {
-  PlPlan best;
-  best.cfg = -1;
-  best.est_us = 1e30;
+// Which kernel family runs a site.  Rules read off tools/tune_conv.py (every choice timed per TSM-R50 site in one process,
+// profiles/r02_tune_conv.txt); differences between neighbouring choices are a few per cent, the rules keep the clear ones:
+//   * 128 output columns: the two-workgroups-per-CU kernels (conv_*_x3_kernel) -- a 256x128 tile never beat them;
+//   * 64 output columns: 256x64 tiles for 3x3 filters (compute-bound: +16 %), the fp32-MFMA 64-wide kernels for 1x1 (HBM-bound);
+//   * multiples of 256 columns: fprop 256x256 tiles when there are exactly 256 columns and K >= 512, else 128x256 tiles for
+//     K >= 512 or K = 64, else the x3 kernels (K = 128 / 256: eight or fewer K-steps cannot hide an 8-wave workgroup's
+//     prologue and epilogue, two smaller workgroups per CU can); dgrad 256x256 tiles except for short K with >= 1024 columns
+//     and for stride-2 3x3 filters (four parity classes with a quarter of the taps each).
+// Returns the tile configuration, or -1 for the kernels that take fp32 weights.  BDVCIL_PL_TILE / bdv_conv_debug_force_tile
+// override the rules wherever the forced tile divides the column count.
+int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride) {
   const int forced = pl_tile_override();
-  for (int c = 0; c < 3; ++c) {
-    const PlCfg& k = kPlCfg[c];
-    if (ncols % k.BN != 0) continue;
-    if (c == 2 && forced != 2 && !(allow_256sq && pl_allow_256sq())) continue;
-    if (ncols % 256 == 0 && c == 1 && forced != 1) continue;  // 256-wide outputs: the activation tile is then split once per 256 columns
-    if (forced >= 0 && forced != c && ncols % kPlCfg[forced].BN == 0) continue;
-    PlPlan p;
-    p.cfg = c;
-    p.MT = (M + k.BM - 1) / k.BM;
-    p.NT = ncols / k.BN;
-    p.nk = nk;
-    p.seg_bytes = (size_t)k.BM * k.BN * sizeof(float);
-    if (ksplit_ok) {
-      p.wk = plan_work_pl(p.MT * p.NT, nk, k.iter_us, p.seg_bytes, ws_bytes, &p.est_us);
-    } else {
-      p.wk.dp_tiles = p.MT * p.NT;
-      p.wk.rem_tiles = 0;
-      p.wk.split = 1;
-      p.est_us = (double)((p.MT * p.NT + 255) / 256) * nk * k.iter_us;
-    }
-    if (p.est_us < best.est_us) best = p;
+  if (forced >= 0 && ncols % kPlCfg[forced].BN == 0) return forced;
+  if (ncols % 64 != 0) return -1;
+  if (ncols % 128 != 0) return taps > 1 ? 3 : -1;
+  if (ncols % 256 != 0) return -1;
+  if (!dgrad) {
+    if (ncols == 256 && nk >= 16) return 2;
+    if (nk >= 16 || nk <= 2) return 0;
+    return -1;
   }
-  return best;
+  if (stride == 2 && taps > 1) return -1;
+  if (nk <= 8 && ncols >= 1024) return -1;
+  return 2;
 }
 
-// The tile configuration (hence the row count of the fused-statistics partials) must not depend on the caller's workspace:
-// it is chosen for the full split budget, and only the K-split is re-planned for the workspace actually passed.
-PlPlan plan_pl_ws(int M, int ncols, int nk, size_t ws_bytes, bool ksplit_ok, bool allow_256sq = true) {
-  PlPlan p = plan_pl(M, ncols, nk, kMaxSplitWorkspace, ksplit_ok, allow_256sq);
-  if (p.cfg >= 0 && ksplit_ok && ws_bytes < kMaxSplitWorkspace)
-    p.wk = plan_work_pl(p.MT * p.NT, nk, kPlCfg[p.cfg].iter_us, p.seg_bytes, ws_bytes, &p.est_us);
+// The tile configuration (hence the row count of the fused-statistics partials) does not depend on the caller's workspace;
+// only the K-split of the remainder tiles does.
+PlPlan plan_pl(int cfg, int M, int ncols, int nk, size_t ws_bytes, bool ksplit_ok) {
+  PlPlan p;
+  p.cfg = cfg;
+  p.est_us = 0.0;
+  if (cfg < 0) return p;
+  const PlCfg& k = kPlCfg[cfg];
+  p.MT = (M + k.BM - 1) / k.BM;
+  p.NT = ncols / k.BN;
+  p.nk = nk;
+  p.seg_bytes = (size_t)k.BM * k.BN * sizeof(float);
+  if (ksplit_ok) {
+    p.wk = plan_work_pl(p.MT * p.NT, nk, k.iter_us, p.seg_bytes, ws_bytes, &p.est_us);
+  } else {
+    p.wk.dp_tiles = p.MT * p.NT;
+    p.wk.rem_tiles = 0;
+    p.wk.split = 1;
+    p.est_us = (double)((p.MT * p.NT + 255) / 256) * nk * k.iter_us;
+  }
   return p;
 }
 
-bool pl_fprop_ok(const bdv_conv_geom* g) { return g->Cin % BK == 0 && g->Cout % 128 == 0; }
-bool pl_dgrad_ok(const bdv_conv_geom* g) { return g->Cout % BK == 0 && g->Cin % 128 == 0; }
+int pl_fprop_cfg(const bdv_conv_geom* g) {
+  if (g->Cin % BK != 0) return -1;
+  return pl_pick(false, g->Cout, g->R * g->S * g->Cin / BK, g->R * g->S, g->stride);
+}
+int pl_dgrad_cfg(const bdv_conv_geom* g) {
+  if (g->Cout % BK != 0) return -1;
+  return pl_pick(true, g->Cin, g->R * g->S * g->Cout / BK, g->R * g->S, g->stride);
+}
+bool pl_fprop_ok(const bdv_conv_geom* g) { return pl_fprop_cfg(g) >= 0; }
+bool pl_dgrad_ok(const bdv_conv_geom* g) { return pl_dgrad_cfg(g) >= 0; }
+
 
 struct WgradPlan {
   bool small;  // 64x64 tiles
@@ -2698,11 +2680,11 @@ extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
   size_t need = p.wk.split > 1 ? (size_t)p.wk.rem_tiles * p.wk.split * p.seg_bytes : 0;
   // the P kernels (bdv_conv_fprop_pl / bdv_conv_dgrad_pl) plan their own K-split
   if (kind == 0 && pl_fprop_ok(gg)) {
-    const PlPlan q = plan_pl(g.M, g.Cout, g.Ktot / BK, kMaxSplitWorkspace, true);
+    const PlPlan q = plan_pl(pl_fprop_cfg(gg), g.M, g.Cout, g.Ktot / BK, kMaxSplitWorkspace, true);
     const size_t n2 = q.wk.split > 1 ? (size_t)q.wk.rem_tiles * q.wk.split * q.seg_bytes : 0;
     need = n2 > need ? n2 : need;
   } else if (kind == 1 && pl_dgrad_ok(gg) && gg->stride == 1) {
-    const PlPlan q = plan_pl(g.M, g.Cin, g.Ktot / BK, kMaxSplitWorkspace, true, false);
+    const PlPlan q = plan_pl(pl_dgrad_cfg(gg), g.M, g.Cin, g.Ktot / BK, kMaxSplitWorkspace, true);
     const size_t n2 = q.wk.split > 1 ? (size_t)q.wk.rem_tiles * q.wk.split * q.seg_bytes : 0;
     need = n2 > need ? n2 : need;
   }
@@ -2863,22 +2845,27 @@ extern "C" size_t bdv_conv_weight_planes_bytes(const bdv_conv_geom* gg) {
 }
 
 extern "C" int bdv_conv_debug_force_tile(int cfg) {
-  BDV_REQUIRE(cfg >= -1 && cfg <= 2, "bdv_conv_debug_force_tile: cfg %d (-1 automatic, 0 = 128x256, 1 = 256x128, 2 = 256x256)", cfg);
+  BDV_REQUIRE(cfg >= -1 && cfg < kNumPlCfg, "bdv_conv_debug_force_tile: cfg %d (-1 automatic, 0 = 128x256, 1 = 256x128, 2 = 256x256, 3 = 256x64)", cfg);
   g_pl_tile_forced = cfg;
   return BDV_OK;
+}
+
+extern "C" int bdv_conv_uses_planes(const bdv_conv_geom* gg, int kind) {
+  if (check_geom(gg, "bdv_conv_uses_planes")) return 0;
+  return kind == 0 ? (pl_fprop_ok(gg) ? 1 : 0) : kind == 1 ? (pl_dgrad_ok(gg) ? 1 : 0) : 0;
 }
 
 extern "C" int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* gg) {
   if (check_geom(gg, "bdv_conv_fprop_pl_stat_rows")) return 0;
   if (!pl_fprop_ok(gg)) return bdv_conv_fprop_stat_rows(gg);
-  const PlPlan p = plan_pl(gg->N * gg->Ho * gg->Wo, gg->Cout, gg->R * gg->S * gg->Cin / BK, kMaxSplitWorkspace, true);
+  const PlPlan p = plan_pl(pl_fprop_cfg(gg), gg->N * gg->Ho * gg->Wo, gg->Cout, gg->R * gg->S * gg->Cin / BK, kMaxSplitWorkspace, true);
   return p.cfg >= 0 ? p.MT : 0;
 }
 
 extern "C" int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* gg) {
   if (check_geom(gg, "bdv_conv_dgrad_pl_stat_rows")) return 0;
   if (!pl_dgrad_ok(gg) || gg->stride != 1) return bdv_conv_dgrad_stat_rows(gg);
-  const PlPlan p = plan_pl(gg->N * gg->H * gg->W, gg->Cin, gg->R * gg->S * gg->Cout / BK, kMaxSplitWorkspace, true, false);
+  const PlPlan p = plan_pl(pl_dgrad_cfg(gg), gg->N * gg->H * gg->W, gg->Cin, gg->R * gg->S * gg->Cout / BK, kMaxSplitWorkspace, true);
   return p.cfg >= 0 ? p.MT : 0;
 }
 
@@ -2919,7 +2906,7 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
   g.Ktot = g.R * g.S * g.Cin;
   BDV_REQUIRE((int64_t)3 * g.Cout * g.Ktot * 2 < (1ll << 31), "bdv_conv_fprop_pl: weight planes exceed 2^31 bytes");
   hipStream_t s = (hipStream_t)stream;
-  const PlPlan p = plan_pl_ws(g.M, g.Cout, g.Ktot / BK, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, true);
+  const PlPlan p = plan_pl(pl_fprop_cfg(gg), g.M, g.Cout, g.Ktot / BK, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, true);
   BDV_REQUIRE(p.cfg >= 0, "bdv_conv_fprop_pl: no tile configuration for Cout=%d", g.Cout);
   // bn_partial has one row per row tile of THIS kernel: bdv_conv_fprop_pl_stat_rows(g)
   const int blocks = p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split;
@@ -2931,7 +2918,7 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
             g.W, g.Cin, g.Cout, g.R, g.stride, p.cfg, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split, p.est_us);
 #define BDV_FPROP_PL(BM_, BN_, WM_, WN_, NB_)                                                                                         \
   do {                                                                                                                                \
-    hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_>), dim3(blocks < 256 ? blocks : 256), dim3(64 * WM_ * WN_), 0, s, x, wp, y, g, p.NT,   \
+    hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y, g, p.NT,   \
                        p.wk, slab, epi);                                                                                              \
     BDV_LAUNCH_CHECK("bdv_conv_fprop_pl");                                                                                            \
     if (p.wk.split > 1) {                                                                                                             \
@@ -2942,7 +2929,8 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
   } while (0)
   if (p.cfg == 0) BDV_FPROP_PL(128, 256, 2, 4, 2);
   else if (p.cfg == 1) BDV_FPROP_PL(256, 128, 4, 2, 2);
-  else BDV_FPROP_PL(256, 256, 2, 4, 1);
+  else if (p.cfg == 2) BDV_FPROP_PL(256, 256, 2, 4, 1);
+  else BDV_FPROP_PL(256, 64, 4, 2, 2);
 #undef BDV_FPROP_PL
   return BDV_OK;
 }
@@ -2977,15 +2965,14 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
   hipStream_t s = (hipStream_t)stream;
   const int st = g.stride;
   const int Mc0 = g.N * ((g.H + st - 1) / st) * ((g.W + st - 1) / st);  // largest parity class
-  // (256 x 256 tiles only when forced: the dgrad epilogue does not fit the register file next to 128 accumulator registers)
-  PlPlan p = plan_pl_ws(st == 1 ? g.M : Mc0, g.Cin, g.Ktot / BK,
-                        workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, st == 1, false);
+  PlPlan p = plan_pl(pl_dgrad_cfg(gg), st == 1 ? g.M : Mc0, g.Cin, g.Ktot / BK,
+                     workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, st == 1);
   BDV_REQUIRE(p.cfg >= 0, "bdv_conv_dgrad_pl: no tile configuration for Cin=%d", g.Cin);
   if (st != 1) p.wk.dp_tiles = ((p.MT + 7) / 8) * 8 * p.NT;  // padded grid per parity class
   // the statistics partial has one row per row tile of THIS kernel
   stat.MT = p.MT;
   const int work_items = p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split;
-  const dim3 grid(st == 1 && work_items > 256 ? 256 : work_items, st * st);  // stride 1: persistent workgroups, one per CU
+  const dim3 grid(work_items, st * st);
   float* slab = (float*)workspace;
   const unsigned short* dp = (const unsigned short*)planes_dgrad;
   if (debug_plan())
@@ -3004,7 +2991,8 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
   } while (0)
   if (p.cfg == 0) BDV_DGRAD_PL(128, 256, 2, 4, 2);
   else if (p.cfg == 1) BDV_DGRAD_PL(256, 128, 4, 2, 2);
-  else BDV_DGRAD_PL(256, 256, 2, 4, 1);
+  else if (p.cfg == 2) BDV_DGRAD_PL(256, 256, 2, 4, 1);
+  else BDV_DGRAD_PL(256, 64, 4, 2, 2);
 #undef BDV_DGRAD_PL
   return BDV_OK;
 }

@@ -145,7 +145,7 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
     ws = _conv_ws(g, 0, x.device, ws_tag)
     part = aff = None
     use_x3 = FPROP_X3 if x3 is None else x3
-    use_pl = use_x3 and USE_PL and g.Cin % 32 == 0 and g.Cout % 128 == 0
+    use_pl = bool(use_x3 and USE_PL and lib().bdv_conv_uses_planes(ctypes.byref(g), 0))
     if bn_stats:
         if affine is not None:
             raise ValueError('conv_fprop: bn_stats and affine exclude each other')
@@ -192,8 +192,8 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
     if add_mask_src is not None:
         _chk(add_mask_src, (g.N * g.H * g.W * g.Cin // 32,), dtype=torch.int32, name='add_mask_src')
     fuse = partial = None
-    use_x3 = (DGRAD_X3 if x3 is None else x3) and g.Cin % 128 == 0
-    use_pl = use_x3 and USE_PL
+    use_x3 = (DGRAD_X3 if x3 is None else x3) and g.Cin % 64 == 0
+    use_pl = bool(use_x3 and USE_PL and lib().bdv_conv_uses_planes(ctypes.byref(g), 1))
     if bn_stats is not None:
         y, mask, mean, invstd = bn_stats
         _chk(y, (g.N, g.H, g.W, g.Cin), name='y')
@@ -214,7 +214,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
                                       ctypes.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), _stream()),
               'bdv_conv_dgrad_pl')
         return dx if bn_stats is None else (dx, partial)
-    if use_x3:
+    if use_x3 and g.Cin % 128 == 0:
         w_t = w.permute(1, 2, 3, 0).contiguous()            # (R, S, Cin, Cout): contraction index contiguous
         check(lib().bdv_conv_dgrad_x3(_p(dy), _p(w), _p(w_t), _p(dx), _p(add_src), _p(add_mask_src), ctypes.byref(g),
                                       ctypes.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), _stream()),

@@ -122,8 +122,11 @@ int bdv_conv_dgrad_x3(const float* dy, const float* w, const float* w_t, float* 
 size_t bdv_conv_weight_planes_bytes(const bdv_conv_geom* g);
 int bdv_conv_split_weights(const float* w, const bdv_conv_geom* g, void* planes_fprop, void* planes_dgrad, void* stream);
 /* Test / A-B hook, process-wide and not thread-safe: force the tile configuration of the two entry points below
- * (0 = 128x256, 1 = 256x128, 2 = 256x256 where the column count allows it; -1 = chosen by the planner's cost model). */
+ * (0 = 128x256, 1 = 256x128, 2 = 256x256, 3 = 256x64, where the tile divides the column count; -1 = the planner's rules). */
 int bdv_conv_debug_force_tile(int cfg);
+/* 1 when bdv_conv_fprop_pl (kind 0) / bdv_conv_dgrad_pl (kind 1) will read the weight planes for this geometry, 0 when it
+ * runs a kernel that takes w (the caller then need not build the planes). */
+int bdv_conv_uses_planes(const bdv_conv_geom* g, int kind);
 int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* g);
 int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* g);
 int bdv_conv_fprop_pl(const float* x, const float* w, const void* planes_fprop, float* y, const bdv_conv_geom* g,

@@ -326,11 +326,13 @@ PL_CASES = [
     (16, 7, 7, 256, 128, 1, 1, 0, 8, 32),       # Cout 128: 256x128 tiles
     (4, 10, 10, 128, 128, 3, 1, 1, 1, 0),
     (8, 8, 8, 256, 256, 1, 2, 0, 1, 0),         # 1x1 stride 2 (downsample)
+    (8, 12, 12, 64, 64, 3, 1, 1, 1, 0),         # 64-channel layer: 256x64 tiles in both directions
+    (16, 9, 9, 256, 64, 1, 1, 0, 8, 32),        # conv1 of a layer-1 bottleneck (shift), ragged M
 ]
 
 
 @pytest.mark.parametrize('case', PL_CASES)
-@pytest.mark.parametrize('tile', [-1, 0, 1, 2])
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 3])
 def test_plane_kernels_every_tile(case, tile, dev):
     """The 8-wave kernels on pre-split weight planes (bdv_conv_fprop_pl / bdv_conv_dgrad_pl), every tile configuration
     forced in turn (-1 = planner's choice): against the CPU reference (2e-5), against the fp32-MFMA kernels (4e-6), with the

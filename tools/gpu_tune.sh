@@ -1,4 +1,3 @@
-# conv-only GPU call: kernel tests, then the per-site table under a few planner settings
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 step() {  # name, limit, command...
@@ -9,7 +8,6 @@ step() {  # name, limit, command...
   tail -n 4 gpurun_out/$name.log
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$name] killed at its limit: stopping"; exit $rc; fi
 }
-step pytest_conv 900 python -m pytest tests/test_conv_gpu.py tests/test_ops_gpu.py -m gpu -q -x
-step bench_conv_pl 200 python tools/bench_conv.py
-BDVCIL_PL_256=1 step bench_conv_pl_256 200 python tools/bench_conv.py
+step pytest_conv 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -x
+step tune_conv 500 python tools/tune_conv.py
 step bench 400 python bench.py --steps 12 --warmup 4 --no-cpu-baseline
