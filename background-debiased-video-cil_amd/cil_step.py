@@ -144,6 +144,10 @@ def icarl_video_mix_training_step(current_model: nn.Module, batch_data: Dict[str
                     base_targets=base)
 
 
+import os as _os
+_MAIN_HIGH_PRIORITY = _os.environ.get('BDVCIL_MAIN_HIGH_PRIORITY', '0') != '0'
+
+
 class TrainEngine:
     """One optimisation step = forward, backward (bucketed gradient all-reduce overlapped), clip, fused SGD."""
 
@@ -153,6 +157,20 @@ class TrainEngine:
             optimizer.set_grad_scale(reducer.grad_scale)
 
     def step(self, batch_data: Dict[str, torch.Tensor], loss_fn=None) -> Dict[str, torch.Tensor]:
+        if _MAIN_HIGH_PRIORITY and torch.cuda.is_available():
+            # The dependent chain (forward, BatchNorm backward -> dgrad -> ...) on a high-priority stream; the weight
+            # gradients, which nothing waits for until the optimizer, stay on the normal-priority side stream and fill in.
+            if getattr(self, '_hi', None) is None:
+                self._hi = torch.cuda.Stream(priority=-1)
+            cur = torch.cuda.current_stream()
+            self._hi.wait_stream(cur)
+            with torch.cuda.stream(self._hi):
+                losses = self._step(batch_data, loss_fn)
+            cur.wait_stream(self._hi)
+            return losses
+        return self._step(batch_data, loss_fn)
+
+    def _step(self, batch_data: Dict[str, torch.Tensor], loss_fn=None) -> Dict[str, torch.Tensor]:
         self.optimizer.zero_grad(set_to_none=True)
         if loss_fn is None:
             losses = base_training_step(self.model, batch_data)

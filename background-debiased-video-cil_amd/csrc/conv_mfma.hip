@@ -695,7 +695,9 @@ __device__ __forceinline__ void mma_stage_x3(const unsigned short* __restrict__ 
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+// BPRE: w points at the F planes of bdv_conv_split_weights instead of the fp32 weights: the weight tile of a K-step is then
+// three contiguous blocks of 64-byte rows, loaded with 16-byte loads and stored as they are (no split VALU for that operand).
+template <int BM, int BN, int WM, int WN, bool BPRE = false>
 __global__ __launch_bounds__(256, 2) void conv_fprop_x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           float* __restrict__ y, Geom g, int NT, Work wk,
                                                           float* __restrict__ slab, FpropEpi epi) {
@@ -721,7 +723,11 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_x3_kernel(const float* __re
   const int frame_bytes = g.H * g.W * g.Cin * 4;
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * frame_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, g.Cout * g.Ktot * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, BPRE ? 3 * g.Cout * g.Ktot * 2 : g.Cout * g.Ktot * 4, 0x00020000);
+  constexpr int BQ = BN * 4 / 256;                    // BPRE: 16-byte loads per plane and thread
+  const int brow = tid >> 2, bc = tid & 3;
+  const int plane_bytes = g.Cout * g.Ktot * 2;
+  int kt_w = it.kb;
 
   int a_base[AP], a_t[AP], a_hi0[AP], a_wi0[AP];
 #pragma unroll
@@ -750,6 +756,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_x3_kernel(const float* __re
   }
 
   float4 ra[AP], rb[BP];
+  u32x4 rbp[BPRE ? 3 * BQ : 1];
   auto load = [&]() {
     const int cls = shift_class(chunk * BK + 4 * kg, g.fold);
     const int koff_a = ((r * g.W + s) * g.Cin + chunk * BK) * 4;
@@ -761,8 +768,17 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_x3_kernel(const float* __re
       // invalid lanes: set the top bit -> beyond num_records -> the load returns zeros
       ra[p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB), 0);
     }
+    if (BPRE) {
 #pragma unroll
-    for (int p = 0; p < BP; ++p) rb[p] = buf_load16(wr, b_base[p], koff_b);
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int q = 0; q < BQ; ++q)
+          rbp[pl * BQ + q] = __builtin_amdgcn_raw_buffer_load_b128(wr, (nt * BN + brow + 64 * q) * 64 + 16 * bc + pl * plane_bytes, kt_w * g.Cout * 64, 0);
+      kt_w += 1;
+    } else {
+#pragma unroll
+      for (int p = 0; p < BP; ++p) rb[p] = buf_load16(wr, b_base[p], koff_b);
+    }
     // advance to the next K-step (branch-free)
     s += 1;
     const int ws_ = (s == g.S) ? 1 : 0;
@@ -780,7 +796,14 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_x3_kernel(const float* __re
   for (int kt = it.kb; kt < it.ke; ++kt) {
     __syncthreads();  // everyone is done reading the previous stage
     store_split3<BM, AP>(As, ra, tid);
-    store_split3<BN, BP>(Bs, rb, tid);
+    if (BPRE) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) *reinterpret_cast<u32x4*>(Bs + (pl * BN + brow + 64 * q) * X3_LDK + 8 * bc) = rbp[pl * BQ + q];
+    } else {
+      store_split3<BN, BP>(Bs, rb, tid);
+    }
     __syncthreads();
     if (kt + 1 < it.ke) load();  // in flight during the MFMAs
     mma_stage_x3<TM, TN, 32 * WM, 32 * WN, BM, BN>(As, Bs, acc, wm0, wn0, lane);
@@ -1097,13 +1120,13 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
   });
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool BPRE = false>
 __global__ __launch_bounds__(256, 2) void conv_dgrad_x3_kernel(const float* __restrict__ dy, const float* __restrict__ wt,
                                                           float* __restrict__ dx, const float* __restrict__ add_src,
                                                           const uint32_t* __restrict__ add_mask, Geom g, int NT, Work wk,
                                                           float* __restrict__ slab, BnStat stat) {
   // bf16-piece variant of conv_dgrad_kernel (see conv_fprop_x3_kernel).  wt = the weights transposed per tap,
-  // [R*S][Cin][Cout], so that the B operand is k-contiguous like dy.
+  // [R*S][Cin][Cout], so that the B operand is k-contiguous like dy; BPRE: wt = the D planes of bdv_conv_split_weights.
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
   static_assert(3 * (BM + BN) * X3_LDK * 2 >= WM * 32 * BN * 4, "the epilogue stages a tile pass in the same LDS");
@@ -1150,7 +1173,11 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_x3_kernel(const float* __re
   const int HcWc = Hc * Wc;
   const int RS = g.R * g.S;
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.N * g.Ho * g.Wo * g.Cout * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, g.Cout * RS * g.Cin * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, BPRE ? 3 * g.Cout * RS * g.Cin * 2 : g.Cout * RS * g.Cin * 4, 0x00020000);
+  constexpr int BQ = BN * 4 / 256;
+  const int brow = tid >> 2, bc = tid & 3;
+  const int plane_bytes = g.Cout * RS * g.Cin * 2;
+  const int nchunk = g.Cout / BK;
 
   int a_base[AP], a_h[AP], a_w[AP];
 #pragma unroll
@@ -1179,6 +1206,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_x3_kernel(const float* __re
   }
 
   float4 ra[AP], rb[BP];
+  u32x4 rbp[BPRE ? 3 * BQ : 1];
   auto load = [&]() {
     const int tap = (r0 + ir * st) * g.S + (s0 + is * st);
     const int koff_a = (chunk * BK - (ir * g.Wo + is) * g.Cout) * 4;
@@ -1188,8 +1216,17 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_x3_kernel(const float* __re
       const bool v = (unsigned)(a_h[p] - ir) < (unsigned)g.Ho && (unsigned)(a_w[p] - is) < (unsigned)g.Wo;
       ra[p] = buf_load16(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB), 0);
     }
+    if (BPRE) {
 #pragma unroll
-    for (int p = 0; p < BP; ++p) rb[p] = buf_load16(wr, b_base[p], koff_b);
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int q = 0; q < BQ; ++q)
+          rbp[pl * BQ + q] = __builtin_amdgcn_raw_buffer_load_b128(wr, (nt * BN + brow + 64 * q) * 64 + 16 * bc + pl * plane_bytes,
+                                                                   (tap * nchunk + chunk) * g.Cin * 64, 0);
+    } else {
+#pragma unroll
+      for (int p = 0; p < BP; ++p) rb[p] = buf_load16(wr, b_base[p], koff_b);
+    }
     is += 1;
     const int w1 = (is == ns) ? 1 : 0;
     is = w1 ? 0 : is;
@@ -1207,7 +1244,14 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_x3_kernel(const float* __re
     for (int kt = it.kb; kt < it.ke; ++kt) {
       __syncthreads();
       store_split3<BM, AP>(As, ra, tid);
-      store_split3<BN, BP>(Bs, rb, tid);
+      if (BPRE) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int q = 0; q < BQ; ++q) *reinterpret_cast<u32x4*>(Bs + (pl * BN + brow + 64 * q) * X3_LDK + 8 * bc) = rbp[pl * BQ + q];
+      } else {
+        store_split3<BN, BP>(Bs, rb, tid);
+      }
       __syncthreads();
       if (kt + 1 < it.ke) load();
       mma_stage_x3<TM, TN, 32 * WM, 32 * WN, BM, BN>(As, Bs, acc, wm0, wn0, lane);
@@ -2525,6 +2569,7 @@ int pl_tile_override() {
 // override the rules wherever the forced tile divides the column count.
 int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride) {
   const int forced = pl_tile_override();
+  if (forced == kNumPlCfg) return -1;  // "none": the kernels of the other family everywhere
   if (forced >= 0 && ncols % kPlCfg[forced].BN == 0) return forced;
   if (ncols % 64 != 0) return -1;
   if (ncols % 128 != 0) return taps > 1 ? 3 : -1;
@@ -2560,6 +2605,13 @@ PlPlan plan_pl(int cfg, int M, int ncols, int nk, size_t ws_bytes, bool ksplit_o
     p.est_us = (double)((p.MT * p.NT + 255) / 256) * nk * k.iter_us;
   }
   return p;
+}
+
+// the two-workgroups-per-CU bf16-piece kernels read their weight operand from the planes as well (BDVCIL_R1_PLANES=0: split it
+// in the K loop, as in round 1)
+bool r1_planes_enabled() {
+  static const bool on = getenv("BDVCIL_R1_PLANES") == nullptr || atoi(getenv("BDVCIL_R1_PLANES")) != 0;
+  return on;
 }
 
 int pl_fprop_cfg(const bdv_conv_geom* g) {
@@ -2699,7 +2751,8 @@ extern "C" int bdv_conv_fprop_stat_rows(const bdv_conv_geom* gg) {
 
 namespace {
 int conv_fprop_impl(const float* x, const float* w, float* y, const bdv_conv_geom* gg, float* bn_partial,
-                    const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream, bool x3) {
+                    const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream, bool x3,
+                    const void* planes_f = nullptr) {
   if (int e = check_geom(gg, "bdv_conv_fprop")) return e;
   BDV_REQUIRE(x && w && y, "bdv_conv_fprop: null pointer");
   FpropEpi epi = {bn_partial, 0, nullptr, nullptr, nullptr, 0};
@@ -2733,7 +2786,10 @@ int conv_fprop_impl(const float* x, const float* w, float* y, const bdv_conv_geo
     else
       hipLaunchKernelGGL((conv_fprop_c4_kernel<128, 64, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, epi);
   } else if (p.wide && x3) {
-    hipLaunchKernelGGL((conv_fprop_x3_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, epi);
+    if (planes_f != nullptr)
+      hipLaunchKernelGGL((conv_fprop_x3_kernel<128, 128, 2, 2, true>), dim3(blocks), dim3(256), 0, s, x, (const float*)planes_f, y, g, p.NT, p.wk, slab, epi);
+    else
+      hipLaunchKernelGGL((conv_fprop_x3_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, epi);
   } else if (p.wide) {
     hipLaunchKernelGGL((conv_fprop_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, p.wk, slab, epi);
   } else {
@@ -2772,7 +2828,7 @@ namespace {
 // w_t != nullptr: the bf16-piece kernel on the per-tap transposed weights (wide tiles only), else the fp32-MFMA kernels
 int conv_dgrad_impl(const float* dy, const float* w, const float* w_t, float* dx, const float* add_src,
                     const uint32_t* add_mask_src, const bdv_conv_geom* gg, const bdv_bn_stat_fuse* bn_stat, void* workspace,
-                    size_t workspace_bytes, void* stream) {
+                    size_t workspace_bytes, void* stream, const void* planes_d = nullptr) {
   if (int e = check_geom(gg, "bdv_conv_dgrad")) return e;
   BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   if (bn_stat != nullptr) {
@@ -2798,7 +2854,7 @@ int conv_dgrad_impl(const float* dy, const float* w, const float* w_t, float* dx
   g.Ktot = g.R * g.S * g.Cout;
   hipStream_t s = (hipStream_t)stream;
   const int st = g.stride;
-  const bool x3 = w_t != nullptr && (g.Cin % 128) == 0;
+  const bool x3 = (w_t != nullptr || planes_d != nullptr) && (g.Cin % 128) == 0;
   BDV_REQUIRE(w_t == nullptr || bdv_aligned16(w_t), "bdv_conv_dgrad_x3: w_t must be 16-byte aligned");
   const FdPlan p = plan_dgrad(g, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, x3);
   const dim3 grid(p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split, st * st);
@@ -2807,7 +2863,10 @@ int conv_dgrad_impl(const float* dy, const float* w, const float* w_t, float* dx
     fprintf(stderr, "[bdv plan] dgrad %dx%d Cin %d Cout %d k%d s%d: tiles %d nk %d -> dp %d rem %d split %d\n", g.H, g.W,
             g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
   if (p.wide && x3)
-    hipLaunchKernelGGL((conv_dgrad_x3_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, dy, w_t, dx, add_src, add_mask_src, g, p.NT, p.wk, slab, stat);
+    if (planes_d != nullptr)
+      hipLaunchKernelGGL((conv_dgrad_x3_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, s, dy, (const float*)planes_d, dx, add_src, add_mask_src, g, p.NT, p.wk, slab, stat);
+    else
+      hipLaunchKernelGGL((conv_dgrad_x3_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, dy, w_t, dx, add_src, add_mask_src, g, p.NT, p.wk, slab, stat);
   else if (p.wide)
     hipLaunchKernelGGL((conv_dgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, dy, w, dx, add_src, add_mask_src, g, p.NT, p.wk, slab, stat);
   else
@@ -2845,14 +2904,16 @@ extern "C" size_t bdv_conv_weight_planes_bytes(const bdv_conv_geom* gg) {
 }
 
 extern "C" int bdv_conv_debug_force_tile(int cfg) {
-  BDV_REQUIRE(cfg >= -1 && cfg < kNumPlCfg, "bdv_conv_debug_force_tile: cfg %d (-1 automatic, 0 = 128x256, 1 = 256x128, 2 = 256x256, 3 = 256x64)", cfg);
+  BDV_REQUIRE(cfg >= -1 && cfg <= kNumPlCfg, "bdv_conv_debug_force_tile: cfg %d (-1 automatic, 0 = 128x256, 1 = 256x128, 2 = 256x256, 3 = 256x64, 4 = none)", cfg);
   g_pl_tile_forced = cfg;
   return BDV_OK;
 }
 
 extern "C" int bdv_conv_uses_planes(const bdv_conv_geom* gg, int kind) {
   if (check_geom(gg, "bdv_conv_uses_planes")) return 0;
-  return kind == 0 ? (pl_fprop_ok(gg) ? 1 : 0) : kind == 1 ? (pl_dgrad_ok(gg) ? 1 : 0) : 0;
+  if (kind == 0) return pl_fprop_ok(gg) || (r1_planes_enabled() && gg->Cin % BK == 0 && gg->Cout % 128 == 0) ? 1 : 0;
+  if (kind == 1) return pl_dgrad_ok(gg) || (r1_planes_enabled() && gg->Cout % BK == 0 && gg->Cin % 128 == 0) ? 1 : 0;
+  return 0;
 }
 
 extern "C" int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* gg) {
@@ -2885,8 +2946,9 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
                                  float* bn_partial, const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes,
                                  void* stream) {
   if (int e = check_geom(gg, "bdv_conv_fprop_pl")) return e;
-  if (planes_fprop == nullptr || !pl_fprop_ok(gg))  // shapes outside the P kernels: the fp32-operand entry point
-    return conv_fprop_impl(x, w, y, gg, bn_partial, affine, workspace, workspace_bytes, stream, true);
+  if (planes_fprop == nullptr || !pl_fprop_ok(gg))  // sites of the two-workgroups-per-CU kernels (weights from the planes too)
+    return conv_fprop_impl(x, w, y, gg, bn_partial, affine, workspace, workspace_bytes, stream, true,
+                           gg->Cin % BK == 0 && r1_planes_enabled() ? planes_fprop : nullptr);
   BDV_REQUIRE(x && y, "bdv_conv_fprop_pl: null pointer");
   FpropEpi epi = {bn_partial, 0, nullptr, nullptr, nullptr, 0};
   if (affine != nullptr) {
@@ -2940,7 +3002,8 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
                                  void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_dgrad_pl")) return e;
   if (planes_dgrad == nullptr || !pl_dgrad_ok(gg))
-    return conv_dgrad_impl(dy, w, nullptr, dx, add_src, add_mask_src, gg, bn_stat, workspace, workspace_bytes, stream);
+    return conv_dgrad_impl(dy, w, nullptr, dx, add_src, add_mask_src, gg, bn_stat, workspace, workspace_bytes, stream,
+                           gg->Cout % BK == 0 && r1_planes_enabled() ? planes_dgrad : nullptr);
   BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   if (bn_stat != nullptr) {
     BDV_REQUIRE(gg->stride == 1, "bdv_conv_dgrad_pl: fused BatchNorm statistics need stride 1");

@@ -24,15 +24,15 @@ from . import kernels as K
 # ---------------------------------------------------------------------------------------------
 # side stream for weight gradients
 # ---------------------------------------------------------------------------------------------
-# In backward, wgrad(l) only feeds the optimizer while dgrad(l) -> BN-backward(l-1) -> ... is the critical chain.
-# Launching the wgrads on a second HIP stream keeps two independent kernels in flight, so the CUs a kernel's last
-# partial wave of workgroups leaves idle (tile-count quantisation on 256 CUs) are filled by the other kernel, and the
-# HBM-bound BN-backward passes overlap the MFMA-bound wgrad.  ``join_side_stream`` must run before gradients are
-# consumed (FusedSGD.step / clip / GradAllReducer / StemFn.backward do it).  Off by default since the 32-deep
-# single-stage conv kernels: the gain shrank to ~1 % and concurrent kernels blur per-kernel timing; enable with
-# BDVCIL_WGRAD_SIDE_STREAM=1.
+# In backward, wgrad(l) only feeds the optimizer while BatchNorm-backward(l) -> dgrad(l) -> BatchNorm-backward(l-1) -> ... is the
+# critical chain.  The wgrads are launched on a second HIP stream: the HBM-bound BatchNorm-backward passes of the chain then
+# run beside the MFMA-bound wgrad of the layer above (the 8-wave conv kernels occupy one workgroup per CU and leave wave
+# slots free), and the CUs a dgrad's last partial round of workgroups leaves idle are filled by wgrad workgroups.
+# ``join_side_stream`` must run before gradients are consumed (FusedSGD.step / clip / GradAllReducer / StemFn.backward do it).
+# Measured on one box, alternating runs (profiles/r02_side_stream.txt): 535.1 / 535.0 clips/s without, 551.5 / 550.5 with.
+# BDVCIL_WGRAD_SIDE_STREAM=0 puts everything back on one stream (one batched split-K reduction per stage then).
 import os as _os
-_SIDE = {'enabled': _os.environ.get('BDVCIL_WGRAD_SIDE_STREAM', '0') != '0', 'streams': {}, 'pending': {}}
+_SIDE = {'enabled': _os.environ.get('BDVCIL_WGRAD_SIDE_STREAM', '1') != '0', 'streams': {}, 'pending': {}}
 
 
 # BatchNorm-backward statistics of a unit taken in the epilogue of the dgrad that produces its output gradient
@@ -113,6 +113,34 @@ def wgrad_overlapped(dy: torch.Tensor, inp: torch.Tensor, geom) -> torch.Tensor:
         t.record_stream(side)
     _SIDE['pending'][idx] = done
     return dw
+
+
+# The downsample branch of a block (1x1 conv + its BatchNorm statistics) depends only on the block input: it can run on the
+# side stream beside conv1 / conv2 / conv3 of the main branch and is joined before the block-output kernel.
+DS_SIDE = _os.environ.get('BDVCIL_DS_SIDE', '1') != '0'
+
+
+def run_on_side_stream(fn, device):
+    """Run ``fn()`` (kernel launches only) on the side stream after everything enqueued on the current stream so far;
+    returns (result, event).  The caller makes the consumer stream wait for the event; tensors created inside are
+    registered with the current stream as well, so their memory is not recycled under the consumer."""
+    main = torch.cuda.current_stream(device)
+    _, side = _side_stream(device)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        K.WS_TAG_SUFFIX = '_side'
+        try:
+            out = fn()
+        finally:
+            K.WS_TAG_SUFFIX = ''
+        done = torch.cuda.Event()
+        done.record(side)
+    for t in (out if isinstance(out, (tuple, list)) else (out,)):
+        if torch.is_tensor(t):
+            t.record_stream(main)
+    return out, done
 
 
 def nhwc_to_nchw_view(x: torch.Tensor) -> torch.Tensor:
@@ -229,9 +257,15 @@ def _block_forward(x, blk, training, params, save):
         u = units[n_main]
         wd, gd, bd = params[3 * n_main:3 * n_main + 3]
         g = u.geom(N, H, W)
+        ds_event = None
         if training:
             # the downsample BatchNorm is applied inside the block-output kernel (res_affine): no identity tensor
-            yd, mean_d, invstd_d, sc_d, sh_d = _conv_bn_forward(x, weight_krsc(wd), g, bns[n_main], gd, bd, training)
+            if DS_SIDE and _SIDE['enabled'] and x.is_cuda:
+                (yd, mean_d, invstd_d, sc_d, sh_d), ds_event = run_on_side_stream(
+                    lambda: _conv_bn_forward(x, weight_krsc(wd), g, bns[n_main], gd, bd, training), x.device)
+                x.record_stream(_side_stream(x.device)[1])
+            else:
+                yd, mean_d, invstd_d, sc_d, sh_d = _conv_bn_forward(x, weight_krsc(wd), g, bns[n_main], gd, bd, training)
             identity, id_affine = yd, (sc_d, sh_d)
         else:
             identity, id_affine = _conv_bn_eval(x, weight_krsc(wd), g, bns[n_main], gd, bd, None, False), None
@@ -250,6 +284,8 @@ def _block_forward(x, blk, training, params, save):
             h, w_ = g.Ho, g.Wo
             continue
         y, mean, invstd, sc, sh = _conv_bn_forward(cur, weight_krsc(wt), g, bns[i], gm, bt, training)
+        if last and has_down and training and ds_event is not None:
+            torch.cuda.current_stream(x.device).wait_event(ds_event)      # the identity branch is needed from here on
         if save:
             a, mask = K.bn_apply(y, sc, sh, identity if last else None, True, want_mask=True,
                                  res_affine=id_affine if last else None)

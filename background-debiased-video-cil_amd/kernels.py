@@ -57,11 +57,14 @@ def make_geom(N, H, W, Cin, Cout, R, S, stride, pad, T=1, fold=0) -> ConvGeom:
 # convolution
 # ---------------------------------------------------------------------------------------------
 
+WS_TAG_SUFFIX = ''     # set while launching on another stream: two streams must not share a K-split workspace
+
+
 def _conv_ws(g: ConvGeom, kind: int, device, tag: str) -> torch.Tensor:
     need = lib().bdv_conv_workspace_bytes(ctypes.byref(g), kind)
     if need == 0:
         check(-1, 'bdv_conv_workspace_bytes')
-    return workspace(need, device, tag)
+    return workspace(need, device, tag + WS_TAG_SUFFIX)
 
 
 import os as _os

@@ -22,7 +22,7 @@ def applicable(c, ncols):
     return ncols % bn == 0
 
 
-print(f'{"site":30s} dir    {"r1 x3":>8s} ' + ' '.join(f'{CFG[c]:>8s}' for c in range(4)) + '   best')
+print(f'{"site":30s} dir    {"r1 x3":>8s} {"r1 planes":>9s} ' + ' '.join(f'{CFG[c]:>8s}' for c in range(4)) + '   best')
 tot = {}
 for (Cin, Cout, k, st, H, cnt, sh) in SHAPES:
     if Cin % 32 != 0:
@@ -35,6 +35,8 @@ for (Cin, Cout, k, st, H, cnt, sh) in SHAPES:
         K.USE_PL = False
         t_old = timeit(fn)
         K.USE_PL = True
+        check(lib().bdv_conv_debug_force_tile(4), 'force')      # two-workgroup kernels with the weights from the planes
+        t_r1p = timeit(fn)
         ts = {}
         for c in range(4):
             if not applicable(c, ncols):
@@ -43,11 +45,12 @@ for (Cin, Cout, k, st, H, cnt, sh) in SHAPES:
             ts[c] = timeit(fn)
         check(lib().bdv_conv_debug_force_tile(-1), 'force')
         t_auto = timeit(fn)
-        best = min([('r1', t_old)] + [(CFG[c], t) for c, t in ts.items()], key=lambda q: q[1])
-        row = f'{str((Cin, Cout, k, st, H)):26s} x{cnt:<2d} {name}  {t_old:8.3f} ' + ' '.join(
+        best = min([('r1', t_old), ('r1p', t_r1p)] + [(CFG[c], t) for c, t in ts.items()], key=lambda q: q[1])
+        row = f'{str((Cin, Cout, k, st, H)):26s} x{cnt:<2d} {name}  {t_old:8.3f} {t_r1p:9.3f} ' + ' '.join(
             f'{ts[c]:8.3f}' if c in ts else f'{"-":>8s}' for c in range(4)) + f'   {best[0]:8s} auto {t_auto:.3f}'
         print(row, flush=True)
-        for key, t in [('r1', t_old), ('auto', t_auto), ('best', best[1])]:
+        for key, t in [('r1', t_old), ('r1p', t_r1p), ('auto', t_auto), ('best', best[1])]:
             tot[(name, key)] = tot.get((name, key), 0.0) + t * cnt
 for name in ('fprop', 'dgrad'):
-    print(f'total {name}: r1 x3 {tot[(name, "r1")]:.2f} ms, planner {tot[(name, "auto")]:.2f} ms, best per site {tot[(name, "best")]:.2f} ms')
+    print(f'total {name}: r1 x3 {tot[(name, "r1")]:.2f} ms, r1 on planes {tot[(name, "r1p")]:.2f} ms, planner {tot[(name, "auto")]:.2f} ms, '
+          f'best per site {tot[(name, "best")]:.2f} ms')
