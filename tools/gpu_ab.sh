@@ -8,6 +8,4 @@ step() {  # name, limit, command...
   tail -n 8 gpurun_out/$name.log | cut -c1-330
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$name] killed at its limit: stopping"; exit $rc; fi
 }
-step pytest_conv 600 python -m pytest tests/test_conv_gpu.py -m gpu -q -x
 step ab_step 400 python tools/ab_step.py 3 10
-step tune_conv 500 python tools/tune_conv.py
