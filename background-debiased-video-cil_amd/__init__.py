@@ -13,6 +13,7 @@ Import as ``bdvcil_amd`` (see ``bdvcil_amd.py`` at the repo root).  Layout:
 * ``cil_step``     training-step arithmetic of BaseCIL / ICARLModel + a step engine
 * ``ddp``          bucketed gradient all-reduce over RCCL
 * ``representation``  predict_step / NME classifier / class means / herding
+* ``resnet3d``     I3D-ResNet50 (ResNet3d / I3DHead / Recognizer3D) on the same kernels (temporal convs as k x 1 convs)
 * ``task_loop``    the CIL task loop (CILTrainer + CILDataModule bookkeeping, same files on disk)
 """
 from . import _lib, kernels  # noqa: F401
@@ -22,6 +23,7 @@ from .resnet_tsm import Nhwc4Frames, ResNetTSM, TemporalShift  # noqa: F401
 from .heads import LSC, AvgConsensus, IncrementalNet, IncrementalTSMHead  # noqa: F401
 from .losses import ACMSmoothCE, CrossEntropyLoss, LSCLoss, SoftTargetCrossEntropy  # noqa: F401
 from .recognizer import CILRecognizer2D, Recognizer2D  # noqa: F401
+from .resnet3d import I3DHead, Recognizer3D, ResNet3d  # noqa: F401
 from .hooks import OutputHook, rgetattr  # noqa: F401
 from .optim import (CILTSMOptimizerConstructor, CILTSMOptimizerConstructorImprovised, FusedSGD, build_lr_scheduler,  # noqa: F401
                     build_optimizer)

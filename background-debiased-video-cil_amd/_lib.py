@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _lib = None
 
@@ -20,7 +20,7 @@ _lib = None
 class ConvGeom(Structure):
     """Mirror of ``bdv_conv_geom``."""
     _fields_ = [(n, c_int32) for n in
-                ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'R', 'S', 'stride', 'pad', 'T', 'fold')]
+                ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'R', 'S', 'stride', 'pad', 'T', 'fold', 'pad_w')]
 
     def key(self):
         return tuple(getattr(self, n) for n, _ in self._fields_)
@@ -56,6 +56,7 @@ SIGNATURES = {
     'bdv_conv_split_weights': (c_int, [P, POINTER(ConvGeom), P, P, P]),
     'bdv_conv_debug_force_tile': (c_int, [c_int]),
     'bdv_conv_uses_planes': (c_int, [POINTER(ConvGeom), c_int]),
+    'bdv_conv_kernel_name': (c_int, [POINTER(ConvGeom), c_int, c_int, c_char_p, c_size_t]),
     'bdv_conv_fprop_pl_stat_rows': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_dgrad_pl_stat_rows': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_fprop_pl': (c_int, [P, P, P, P, POINTER(ConvGeom), P, POINTER(ConvAffine), P, c_size_t, P]),
@@ -79,6 +80,8 @@ SIGNATURES = {
     'bdv_nchw3_to_nhwc4': (c_int, [P, P, c_int, c_int, c_int, P]),
     'bdv_maxpool_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_maxpool_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_maxpool_t2_fwd': (c_int, [P, P, P, c_int64, c_int64, P]),
+    'bdv_maxpool_t2_bwd': (c_int, [P, P, P, c_int64, c_int64, P]),
     'bdv_bn_relu_maxpool_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_avgpool_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'bdv_avgpool_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),

@@ -26,7 +26,7 @@ namespace {
 constexpr int BK = 32;
 
 struct Geom {
-  int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, T, fold;
+  int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, pad_w, T, fold;  // pad: rows (H), pad_w: columns (W)
   int M;     // GEMM rows: N*Ho*Wo (fprop / wgrad reduction length), N*H*W (dgrad)
   int Ktot;  // fprop: R*S*Cin ; dgrad: R*S*Cout ; wgrad: row length of dw = R*S*Cin
   float rcp_HoWo, rcp_Wo;  // fast division helpers (dividends < 2^22)
@@ -575,8 +575,8 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_kernel(const float* __restr
     fast_divmod(rem, g.Wo, g.rcp_Wo, ho, wo);
     a_t[p] = n % g.T;
     a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);  // rows past M fail every bounds test
-    a_wi0[p] = wo * g.stride - g.pad;
-    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad) * g.Cin * 4 + 16 * kg;
+    a_wi0[p] = wo * g.stride - g.pad_w;
+    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad_w) * g.Cin * 4 + 16 * kg;
   }
   int b_base[BP];
 #pragma unroll
@@ -739,8 +739,8 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_x3_kernel(const float* __re
     fast_divmod(rem, g.Wo, g.rcp_Wo, ho, wo);
     a_t[p] = n % g.T;
     a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);  // rows past M fail every bounds test
-    a_wi0[p] = wo * g.stride - g.pad;
-    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad) * g.Cin * 4 + 16 * kg;
+    a_wi0[p] = wo * g.stride - g.pad_w;
+    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad_w) * g.Cin * 4 + 16 * kg;
   }
   int b_base[BP];
 #pragma unroll
@@ -916,8 +916,8 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __re
     const int rem = mm - n * HoWo;
     const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
     a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);
-    a_wi0[p] = wo * g.stride - g.pad;
-    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad) * 16;
+    a_wi0[p] = wo * g.stride - g.pad_w;
+    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad_w) * 16;
   }
   float4 ra[AP], rb[BP];
   auto load = [&](int kt) {
@@ -1003,10 +1003,10 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
   const int Hc = (g.H - ph + st - 1) / st, Wc = (g.W - pw + st - 1) / st;
   const int Mc = g.N * Hc * Wc;
   const int MT = (Mc + BM - 1) / BM;
-  const int r0 = (ph + g.pad) % st, s0 = (pw + g.pad) % st;
+  const int r0 = (ph + g.pad) % st, s0 = (pw + g.pad_w) % st;
   const int nr = r0 < g.R ? (g.R - r0 + st - 1) / st : 0;
   const int ns = s0 < g.S ? (g.S - s0 + st - 1) / st : 0;
-  const int bh = (ph + g.pad - r0) / st, bw = (pw + g.pad - s0) / st;
+  const int bh = (ph + g.pad - r0) / st, bw = (pw + g.pad_w - s0) / st;
   const int ntap = nr * ns;
   const int nk = ntap * g.Cout / BK;  // 0 for a class no filter tap reaches (e.g. 1x1 stride 2, odd pixels)
 
@@ -1141,10 +1141,10 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_x3_kernel(const float* __re
   const int Hc = (g.H - ph + st - 1) / st, Wc = (g.W - pw + st - 1) / st;
   const int Mc = g.N * Hc * Wc;
   const int MT = (Mc + BM - 1) / BM;
-  const int r0 = (ph + g.pad) % st, s0 = (pw + g.pad) % st;
+  const int r0 = (ph + g.pad) % st, s0 = (pw + g.pad_w) % st;
   const int nr = r0 < g.R ? (g.R - r0 + st - 1) / st : 0;
   const int ns = s0 < g.S ? (g.S - s0 + st - 1) / st : 0;
-  const int bh = (ph + g.pad - r0) / st, bw = (pw + g.pad - s0) / st;
+  const int bh = (ph + g.pad - r0) / st, bw = (pw + g.pad_w - s0) / st;
   const int ntap = nr * ns;
   const int nk = ntap * g.Cout / BK;  // 0 for a class no filter tap reaches (e.g. 1x1 stride 2, odd pixels)
 
@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const float* __restr
       b_cok[p] = true;
     }
     b_r[p] = tap / g.S - g.pad;
-    b_s[p] = tap % g.S - g.pad;
+    b_s[p] = tap % g.S - g.pad_w;
     b_cls[p] = shift_class(ci, g.fold);
     b_off[p] = ((b_r[p] * g.W + b_s[p]) * g.Cin + ci) * 4 + b_cls[p] * frame_bytes;
   }
@@ -1538,7 +1538,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const float* __re
       b_cok[p] = true;
     }
     b_r[p] = tap / g.S - g.pad;
-    b_s[p] = tap % g.S - g.pad;
+    b_s[p] = tap % g.S - g.pad_w;
     b_cls[p] = shift_class(ci, g.fold);
     b_off[p] = ((b_r[p] * g.W + b_s[p]) * g.Cin + ci) * 4 + b_cls[p] * frame_bytes;
   }
@@ -1885,8 +1885,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
     fast_divmod(rem, g.Wo, g.rcp_Wo, ho, wo);
     a_t[p] = n % g.T;
     a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);  // rows past M fail every bounds test
-    a_wi0[p] = wo * g.stride - g.pad;
-    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad) * g.Cin * 4 + 16 * kg;
+    a_wi0[p] = wo * g.stride - g.pad_w;
+    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad_w) * g.Cin * 4 + 16 * kg;
   }
   int b_base[BPP];
   const bool b_active = BN * 4 >= NTHR || tid < BN * 4;   // a 64-row weight tile is loaded by the first four waves only
@@ -2007,10 +2007,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
   const int Hc = (g.H - ph + st - 1) / st, Wc = (g.W - pw + st - 1) / st;
   const int Mc = g.N * Hc * Wc;
   const int MT = (Mc + BM - 1) / BM;
-  const int r0 = (ph + g.pad) % st, s0 = (pw + g.pad) % st;
+  const int r0 = (ph + g.pad) % st, s0 = (pw + g.pad_w) % st;
   const int nr = r0 < g.R ? (g.R - r0 + st - 1) / st : 0;
   const int ns = s0 < g.S ? (g.S - s0 + st - 1) / st : 0;
-  const int bh = (ph + g.pad - r0) / st, bw = (pw + g.pad - s0) / st;
+  const int bh = (ph + g.pad - r0) / st, bw = (pw + g.pad_w - s0) / st;
   const int ntap = nr * ns;
   const int nk = ntap * g.Cout / BK;  // 0 for a class no filter tap reaches (e.g. 1x1 stride 2, odd pixels)
 
@@ -2235,7 +2235,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pl_kernel(const float* __re
   const int per_tap = g.Cin / BN;
   const int tap = nt / per_tap;
   const int ci0 = (nt - tap * per_tap) * BN;
-  const int b_r = tap / g.S - g.pad, b_s = tap % g.S - g.pad;
+  const int b_r = tap / g.S - g.pad, b_s = tap % g.S - g.pad_w;
   int b_krow[BP], b_off[BP], b_cls[BP];
 #pragma unroll
   for (int p = 0; p < BP; ++p) {
@@ -2375,7 +2375,8 @@ int check_geom(const bdv_conv_geom* g, const char* who) {
   BDV_REQUIRE(g->Cout > 0 && g->Cout % 64 == 0, "%s: Cout=%d must be a multiple of 64", who, g->Cout);
   BDV_REQUIRE(g->R > 0 && g->S > 0 && g->pad >= 0, "%s: bad filter", who);
   BDV_REQUIRE(g->stride == 1 || g->stride == 2, "%s: stride %d unsupported", who, g->stride);
-  BDV_REQUIRE(g->Ho == (g->H + 2 * g->pad - g->R) / g->stride + 1 && g->Wo == (g->W + 2 * g->pad - g->S) / g->stride + 1,
+  const int pad_w = g->pad_w < 0 ? g->pad : g->pad_w;
+  BDV_REQUIRE(g->Ho == (g->H + 2 * g->pad - g->R) / g->stride + 1 && g->Wo == (g->W + 2 * pad_w - g->S) / g->stride + 1,
               "%s: Ho/Wo inconsistent with H/W/pad/stride", who);
   BDV_REQUIRE(g->Cin % BK == 0 || g->Cin == 4, "%s: Cin=%d must be a multiple of 32 (or exactly 4)", who, g->Cin);
   if (g->fold > 0) {
@@ -2396,7 +2397,7 @@ int check_geom(const bdv_conv_geom* g, const char* who) {
 Geom make_geom(const bdv_conv_geom* g) {
   Geom d;
   d.N = g->N; d.H = g->H; d.W = g->W; d.Cin = g->Cin; d.Ho = g->Ho; d.Wo = g->Wo; d.Cout = g->Cout;
-  d.R = g->R; d.S = g->S; d.stride = g->stride; d.pad = g->pad;
+  d.R = g->R; d.S = g->S; d.stride = g->stride; d.pad = g->pad; d.pad_w = g->pad_w < 0 ? g->pad : g->pad_w;
   d.T = g->fold > 0 ? g->T : 1;
   d.fold = g->fold;
   d.M = 0; d.Ktot = 0;
@@ -2906,6 +2907,47 @@ extern "C" size_t bdv_conv_weight_planes_bytes(const bdv_conv_geom* gg) {
 extern "C" int bdv_conv_debug_force_tile(int cfg) {
   BDV_REQUIRE(cfg >= -1 && cfg <= kNumPlCfg, "bdv_conv_debug_force_tile: cfg %d (-1 automatic, 0 = 128x256, 1 = 256x128, 2 = 256x256, 3 = 256x64, 4 = none)", cfg);
   g_pl_tile_forced = cfg;
+  return BDV_OK;
+}
+
+// Name of the main kernel a call will launch (as rocprofv3 prints it, without the anonymous namespace): for profiles and
+// bench.py's per-kernel accounting.  kind 0 = fprop, 1 = dgrad, 2 = wgrad; arith 0 = fp32 MFMA entry points, 1 = the default
+// bf16-piece entry points (bdv_conv_fprop_pl / bdv_conv_dgrad_pl / bdv_conv_wgrad_partial_pl).
+extern "C" int bdv_conv_kernel_name(const bdv_conv_geom* gg, int kind, int arith, char* out, size_t n) {
+  if (int e = check_geom(gg, "bdv_conv_kernel_name")) return e;
+  BDV_REQUIRE(out && n > 0 && kind >= 0 && kind <= 2, "bdv_conv_kernel_name: bad argument");
+  const bool c4 = gg->Cin % BK != 0;
+  if (kind == 0) {
+    const int cfg = arith ? pl_fprop_cfg(gg) : -1;
+    if (cfg >= 0) {
+      const int wm = cfg == 0 || cfg == 2 ? 2 : 4;
+      snprintf(out, n, "conv_fprop_pl_kernel<%d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, wm, 8 / wm, kPlCfg[cfg].nbuf);
+    } else if (c4) {
+      snprintf(out, n, "conv_fprop_c4_kernel<128, %d, 2, 2>", gg->Cout % 128 == 0 ? 128 : 64);
+    } else if (gg->Cout % 128 == 0 && arith) {
+      snprintf(out, n, "conv_fprop_x3_kernel<128, 128, 2, 2, %s>", r1_planes_enabled() ? "true" : "false");
+    } else {
+      snprintf(out, n, "conv_fprop_kernel<128, %d, 2, 2>", gg->Cout % 128 == 0 ? 128 : 64);
+    }
+  } else if (kind == 1) {
+    const int cfg = arith ? pl_dgrad_cfg(gg) : -1;
+    if (cfg >= 0) {
+      const int wm = cfg == 0 || cfg == 2 ? 2 : 4;
+      snprintf(out, n, "conv_dgrad_pl_kernel<%d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, wm, 8 / wm, kPlCfg[cfg].nbuf);
+    } else if (gg->Cin % 128 == 0 && arith) {
+      snprintf(out, n, "conv_dgrad_x3_kernel<128, 128, 2, 2, %s>", r1_planes_enabled() ? "true" : "false");
+    } else {
+      snprintf(out, n, "conv_dgrad_kernel<128, %d, 2, 2>", gg->Cin % 128 == 0 ? 128 : 64);
+    }
+  } else {
+    if (arith && pl_wgrad_ok(gg)) {
+      const WgradPlPlan p = plan_wgrad_pl(gg);
+      snprintf(out, n, "conv_wgrad_pl_kernel<%d, %d", p.BM, p.BN);
+    } else {
+      const WgradPlan p = plan_wgrad(gg);
+      snprintf(out, n, "conv_wgrad_kernel<%d, %d, 2, 2", p.small ? 64 : 128, p.small ? 64 : 128);
+    }
+  }
   return BDV_OK;
 }
 

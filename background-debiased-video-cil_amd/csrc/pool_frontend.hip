@@ -256,6 +256,74 @@ int ew_grid(int64_t n) {
 
 }  // namespace
 
+namespace {
+// MaxPool3d((2,1,1), stride (2,1,1)) of UPSTREAM mmaction ResNet3d (pool2, between layer1 and layer2 of I3D): the larger of
+// frames 2t and 2t + 1 of a clip, element by element.  sel: 1 bit per output element, set when the second frame won (ties
+// go to the first frame, as torch's max-pool does); the backward routes the gradient by it and writes zeros elsewhere.
+__global__ __launch_bounds__(256) void maxpool_t2_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ out,
+                                                             uint32_t* __restrict__ sel, int64_t frame4, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {   // n4, stride: multiples of 8
+    const int64_t f = i / frame4, r = i - f * frame4;
+    const float4 a = x[(2 * f) * frame4 + r], b = x[(2 * f + 1) * frame4 + r];
+    float4 o;
+    unsigned m = 0;
+    o.x = b.x > a.x ? (m |= 1u, b.x) : a.x;
+    o.y = b.y > a.y ? (m |= 2u, b.y) : a.y;
+    o.z = b.z > a.z ? (m |= 4u, b.z) : a.z;
+    o.w = b.w > a.w ? (m |= 8u, b.w) : a.w;
+    out[i] = o;
+    m <<= 4 * (threadIdx.x & 7);
+    m |= __shfl_xor(m, 1, 64);
+    m |= __shfl_xor(m, 2, 64);
+    m |= __shfl_xor(m, 4, 64);
+    if ((threadIdx.x & 7) == 0) sel[i >> 3] = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_t2_bwd_kernel(const float4* __restrict__ dout, const uint32_t* __restrict__ sel,
+                                                             float4* __restrict__ dx, int64_t frame4, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int64_t f = i / frame4, r = i - f * frame4;
+    const unsigned nib = (sel[i >> 3] >> (4 * (int)(i & 7))) & 0xFu;
+    const float4 g = dout[i];
+    float4 a, b;
+    a.x = (nib & 1u) ? 0.f : g.x; b.x = (nib & 1u) ? g.x : 0.f;
+    a.y = (nib & 2u) ? 0.f : g.y; b.y = (nib & 2u) ? g.y : 0.f;
+    a.z = (nib & 4u) ? 0.f : g.z; b.z = (nib & 4u) ? g.z : 0.f;
+    a.w = (nib & 8u) ? 0.f : g.w; b.w = (nib & 8u) ? g.w : 0.f;
+    dx[(2 * f) * frame4 + r] = a;
+    dx[(2 * f + 1) * frame4 + r] = b;
+  }
+}
+}  // namespace
+
+extern "C" int bdv_maxpool_t2_fwd(const float* x, float* out, uint32_t* sel, int64_t frames_out, int64_t frame_elems, void* stream) {
+  BDV_REQUIRE(x && out && sel && frames_out > 0 && frame_elems > 0 && frame_elems % 32 == 0, "bdv_maxpool_t2_fwd: bad argument");
+  BDV_REQUIRE(bdv_aligned16(x) && bdv_aligned16(out), "bdv_maxpool_t2_fwd: alignment");
+  const int64_t n4 = frames_out * frame_elems / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(maxpool_t2_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)out, sel,
+                     frame_elems / 4, n4);
+  BDV_LAUNCH_CHECK("bdv_maxpool_t2_fwd");
+  return BDV_OK;
+}
+
+extern "C" int bdv_maxpool_t2_bwd(const float* dout, const uint32_t* sel, float* dx, int64_t frames_out, int64_t frame_elems,
+                                  void* stream) {
+  BDV_REQUIRE(dout && dx && sel && frames_out > 0 && frame_elems > 0 && frame_elems % 32 == 0, "bdv_maxpool_t2_bwd: bad argument");
+  BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(dx), "bdv_maxpool_t2_bwd: alignment");
+  const int64_t n4 = frames_out * frame_elems / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(maxpool_t2_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)dout, sel, (float4*)dx,
+                     frame_elems / 4, n4);
+  BDV_LAUNCH_CHECK("bdv_maxpool_t2_bwd");
+  return BDV_OK;
+}
+
 extern "C" int bdv_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream) {
   BDV_REQUIRE(x && out && N > 0 && H > 0 && W > 0, "bdv_nchw3_to_nhwc4: bad argument");
   BDV_REQUIRE(bdv_aligned16(out), "bdv_nchw3_to_nhwc4: alignment");

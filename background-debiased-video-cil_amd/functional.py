@@ -154,9 +154,26 @@ def nchw_view_to_nhwc(x: torch.Tensor) -> torch.Tensor:
 
 def weight_krsc(w: torch.Tensor) -> torch.Tensor:
     """OIHW parameter (channels_last storage) -> (Cout,R,S,Cin) contiguous view (copy only if the
-    parameter is not channels_last, e.g. a foreign checkpoint tensor assigned by hand)."""
+    parameter is not channels_last, e.g. a foreign checkpoint tensor assigned by hand).  A 5-D Conv3d weight
+    (Cout, Cin, kt, kh, kw) in channels_last_3d storage gives (Cout, kt, 1, Cin) for a kt x 1 x 1 filter and
+    (Cout, kh, kw, Cin) for a 1 x kh x kw filter (the two kinds an I3D bottleneck has)."""
+    if w.dim() == 5:
+        co, ci, kt, kh, kw = w.shape
+        if kt > 1 and (kh > 1 or kw > 1):
+            raise NotImplementedError('weight_krsc: a filter that is both temporal and spatial (only the I3D stem has one)')
+        v = w.permute(0, 2, 3, 4, 1)
+        v = v if v.is_contiguous() else v.contiguous()
+        return v.reshape(co, kt, 1, ci) if kt > 1 else v.reshape(co, kh, kw, ci)
     v = w.permute(0, 2, 3, 1)
     return v if v.is_contiguous() else v.contiguous()
+
+
+def grad_like_weight(dw_krsc: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """(Cout,R,S,Cin) kernel output -> a gradient of the parameter's logical shape (a view: its storage is the parameter's)."""
+    if w.dim() == 5:
+        co, ci, kt, kh, kw = w.shape
+        return dw_krsc.reshape(co, kt, kh, kw, ci).permute(0, 4, 1, 2, 3)
+    return dw_krsc.permute(0, 3, 1, 2)
 
 
 class UnitSpec:
@@ -169,6 +186,26 @@ class UnitSpec:
 
     def geom(self, N, H, W):
         return K.make_geom(N, H, W, self.cin, self.cout, self.k, self.k, self.stride, self.pad, self.T, self.fold)
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.pad - self.k) // self.stride + 1, (W + 2 * self.pad - self.k) // self.stride + 1
+
+
+class TemporalUnitSpec(UnitSpec):
+    """kt x 1 x 1 convolution + BN(+ReLU) of an I3D bottleneck: per frame nothing changes spatially; the conv runs on the
+    [B][T][H*W][C] view of the frames (``frames`` per clip = T)."""
+
+    def __init__(self, cin, cout, kt, relu, frames):
+        super().__init__(cin, cout, 1, 1, 0, relu)
+        self.kt, self.frames = kt, frames
+
+    def geom(self, N, H, W):
+        if N % self.frames:
+            raise ValueError(f'{N} frames are not whole clips of {self.frames}')
+        return K.make_temporal_geom(N // self.frames, self.frames, H, W, self.cin, self.cout, self.kt)
+
+    def out_hw(self, H, W):
+        return H, W
 
 
 def _conv_bn_forward(x, w_krsc, g, bn, gamma, beta, training):
@@ -280,10 +317,11 @@ def _block_forward(x, blk, training, params, save):
         geoms.append(g)
         last = i == n_main - 1
         if not training:     # eval: conv + folded BatchNorm (+ identity) + ReLU in one kernel
-            cur = _conv_bn_eval(cur, weight_krsc(wt), g, bns[i], gm, bt, identity if last else None, True)
-            h, w_ = g.Ho, g.Wo
+            h, w_ = u.out_hw(h, w_)
+            cur = _conv_bn_eval(cur, weight_krsc(wt), g, bns[i], gm, bt, identity if last else None, True).view(N, h, w_, u.cout)
             continue
         y, mean, invstd, sc, sh = _conv_bn_forward(cur, weight_krsc(wt), g, bns[i], gm, bt, training)
+        y = y.view(N, *u.out_hw(h, w_), u.cout)          # frames view (a temporal geometry describes another view of it)
         if last and has_down and training and ds_event is not None:
             torch.cuda.current_stream(x.device).wait_event(ds_event)      # the identity branch is needed from here on
         if save:
@@ -295,7 +333,7 @@ def _block_forward(x, blk, training, params, save):
         else:
             a = K.bn_apply(y, sc, sh, identity if last else None, True, res_affine=id_affine if last else None)
         cur = a
-        h, w_ = g.Ho, g.Wo
+        h, w_ = u.out_hw(h, w_)
     if save and has_down:
         saved += [yd, mean_d, invstd_d]
         geoms.append(units[n_main].geom(N, H, W))
@@ -334,7 +372,7 @@ def _block_backward(saved, params, geoms, n_main, has_down, dout, need_params, n
                                             stat_partial=part)
         grads[3 * i + 1], grads[3 * i + 2] = dg, db
         if dw is not None:
-            grads[3 * i] = dw.permute(0, 3, 1, 2)
+            grads[3 * i] = grad_like_weight(dw, wt)
         part = None
         if i > 0:
             gi = geoms[i]
@@ -343,6 +381,7 @@ def _block_backward(saved, params, geoms, n_main, has_down, dout, need_params, n
                 d, part = K.conv_dgrad(dy, weight_krsc(wt), gi, bn_stats=(ys[i - 1], masks[i - 1], means[i - 1], invstds[i - 1]))
             else:
                 d = K.conv_dgrad(dy, weight_krsc(wt), gi)
+            d = d.view_as(inp)                     # frames view (the geometry of a temporal conv names another view)
         else:
             dy_first = dy
 
@@ -356,7 +395,7 @@ def _block_backward(saved, params, geoms, n_main, has_down, dout, need_params, n
         dyd, dgd, dbd, dwd = _bn_wgrad_backward(dout, out_mask, yd, gd, mean_d, invstd_d, x, gdn, need_params[3 * n_main])
         grads[3 * n_main + 1], grads[3 * n_main + 2] = dgd, dbd
         if dwd is not None:
-            grads[3 * n_main] = dwd.permute(0, 3, 1, 2)
+            grads[3 * n_main] = grad_like_weight(dwd, wd)
         if need_dx:
             dx_id = K.conv_dgrad(dyd, weight_krsc(wd), gdn)
             dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), geoms[0], add_src=dx_id, bn_stats=stats)
@@ -365,6 +404,8 @@ def _block_backward(saved, params, geoms, n_main, has_down, dout, need_params, n
         dx = K.conv_dgrad(dy_first, weight_krsc(params[0]), geoms[0], add_src=dout, add_mask_src=out_mask, bn_stats=stats)
     if stats is not None and dx is not None:
         dx, prev_partial = dx
+    if dx is not None:
+        dx = dx.view_as(x)
     return dx, grads, prev_partial
 
 

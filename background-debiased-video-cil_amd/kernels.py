@@ -38,6 +38,21 @@ def _chk(t: torch.Tensor, shape: Optional[Sequence[int]] = None, dtype=torch.flo
     return t
 
 
+def _chk_conv(t: torch.Tensor, shape, g, name):
+    """Operand check of a convolution.  A geometry marked ``frames_view`` (a k x 1 temporal convolution described on the
+    [B][T][H*W][C] view) takes the usual [B*T][H][W][C] tensors of the same storage: element count and channel count must
+    agree, the kernel only sees the pointer."""
+    if getattr(g, 'frames_view', False):
+        _chk(t, None, name=name)
+        n = 1
+        for d in shape:
+            n *= d
+        if t.numel() != n or t.shape[-1] != shape[-1]:
+            raise ValueError(f'{name}: shape {tuple(t.shape)} is not a view of {tuple(shape)}')
+        return t
+    return _chk(t, shape, name=name)
+
+
 def workspace(nbytes: int, device, tag='ws') -> torch.Tensor:
     key = (torch.device(device).index or 0, tag)
     cur = _WS.get(key)
@@ -47,10 +62,20 @@ def workspace(nbytes: int, device, tag='ws') -> torch.Tensor:
     return cur
 
 
-def make_geom(N, H, W, Cin, Cout, R, S, stride, pad, T=1, fold=0) -> ConvGeom:
+def make_geom(N, H, W, Cin, Cout, R, S, stride, pad, T=1, fold=0, pad_w=None) -> ConvGeom:
+    """``pad`` pads rows and columns unless ``pad_w`` gives the column padding separately (k x 1 temporal convolutions)."""
+    pw = pad if pad_w is None else pad_w
     Ho = (H + 2 * pad - R) // stride + 1
-    Wo = (W + 2 * pad - S) // stride + 1
-    return ConvGeom(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, T, fold)
+    Wo = (W + 2 * pw - S) // stride + 1
+    return ConvGeom(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, T, fold, -1 if pad_w is None else pad_w)
+
+
+def make_temporal_geom(B, T, H, W, Cin, Cout, kt) -> ConvGeom:
+    """k x 1 x 1 temporal convolution (stride 1, padding k // 2) of [B*T][H][W][C] frames, as a k x 1 convolution on the
+    [B][T][H*W][C] view of the same storage (I3D Bottleneck3d.conv1 with inflate, configs/_base_/models/i3d_r50.py:13)."""
+    g = make_geom(B, T, H * W, Cin, Cout, kt, 1, 1, kt // 2, pad_w=0)
+    g.frames_view = True
+    return g
 
 
 # ---------------------------------------------------------------------------------------------
@@ -135,16 +160,25 @@ def weight_planes(w: torch.Tensor, g: ConvGeom):
     return ent[2][:nbytes], ent[2][nbytes:]
 
 
+def conv_kernel_name(g: ConvGeom, kind: str, x3: Optional[bool] = None) -> str:
+    """Name of the main kernel ``conv_fprop`` / ``conv_dgrad`` / ``conv_wgrad(_partial)`` launches for this geometry."""
+    k = {'fprop': 0, 'dgrad': 1, 'wgrad': 2}[kind]
+    flag = (FPROP_X3, DGRAD_X3, WGRAD_X3)[k] if x3 is None else x3
+    buf = ctypes.create_string_buffer(128)
+    check(lib().bdv_conv_kernel_name(ctypes.byref(g), k, int(bool(flag)), buf, 128), 'bdv_conv_kernel_name')
+    return buf.value.decode()
+
+
 def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torch.Tensor] = None,
                ws_tag: str = 'conv', bn_stats: bool = False, affine=None, x3: Optional[bool] = None):
     """x (N,H,W,Cin) NHWC, w (Cout,R,S,Cin) -> y (N,Ho,Wo,Cout); with bn_stats also the fused BatchNorm partial
     sums (float[2][rows][Cout]) for ``bn_train_finalize``.
     ``affine = (scale, shift, residual | None, relu)``: eval-mode BatchNorm folded into the epilogue,
     y = relu?(conv * scale + shift (+ residual))."""
-    _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
+    _chk_conv(x, (g.N, g.H, g.W, g.Cin), g, 'x')
     _chk(w, (g.Cout, g.R, g.S, g.Cin), name='w')
     y = out if out is not None else torch.empty((g.N, g.Ho, g.Wo, g.Cout), dtype=torch.float32, device=x.device)
-    _chk(y, (g.N, g.Ho, g.Wo, g.Cout), name='y')
+    _chk_conv(y, (g.N, g.Ho, g.Wo, g.Cout), g, 'y')
     ws = _conv_ws(g, 0, x.device, ws_tag)
     part = aff = None
     use_x3 = FPROP_X3 if x3 is None else x3
@@ -161,7 +195,7 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
         _chk(scale, (g.Cout,), name='scale')
         _chk(shift, (g.Cout,), name='shift')
         if res is not None:
-            _chk(res, (g.N, g.Ho, g.Wo, g.Cout), name='residual')
+            _chk_conv(res, (g.N, g.Ho, g.Wo, g.Cout), g, 'residual')
         aff = ConvAffine(scale.data_ptr(), shift.data_ptr(), res.data_ptr() if res is not None else None, int(bool(relu)))
     if use_pl:
         planes_f, _ = weight_planes(w, g)
@@ -184,12 +218,12 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
     """``bn_stats = (y, relu_mask | None, mean, invstd)`` of the conv unit whose output gradient this dgrad produces:
     the BatchNorm-backward statistics are then taken in the epilogue and ``(dx, partial)`` is returned; pass ``partial``
     to ``bn_backward(stat_partial=...)``.  Needs stride 1 and no temporal shift."""
-    _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
+    _chk_conv(dy, (g.N, g.Ho, g.Wo, g.Cout), g, 'dy')
     _chk(w, (g.Cout, g.R, g.S, g.Cin), name='w')
     dx = out if out is not None else torch.empty((g.N, g.H, g.W, g.Cin), dtype=torch.float32, device=dy.device)
-    _chk(dx, (g.N, g.H, g.W, g.Cin), name='dx')
+    _chk_conv(dx, (g.N, g.H, g.W, g.Cin), g, 'dx')
     if add_src is not None:
-        _chk(add_src, (g.N, g.H, g.W, g.Cin), name='add_src')
+        _chk_conv(add_src, (g.N, g.H, g.W, g.Cin), g, 'add_src')
         if add_src.data_ptr() == dx.data_ptr() and g.fold > 0:
             raise ValueError('conv_dgrad: in-place add_src is not allowed with a temporal shift (scatter epilogue)')
     if add_mask_src is not None:
@@ -199,7 +233,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
     use_pl = bool(use_x3 and USE_PL and lib().bdv_conv_uses_planes(ctypes.byref(g), 1))
     if bn_stats is not None:
         y, mask, mean, invstd = bn_stats
-        _chk(y, (g.N, g.H, g.W, g.Cin), name='y')
+        _chk_conv(y, (g.N, g.H, g.W, g.Cin), g, 'y')
         _chk(mean, (g.Cin,), name='mean')
         _chk(invstd, (g.Cin,), name='invstd')
         if mask is not None:
@@ -231,8 +265,8 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, dw: Optional[torch.Tensor] = None,
                beta: float = 0.0, ws_tag: str = 'wgrad', x3: Optional[bool] = None) -> torch.Tensor:
     """dw = beta * dw + dy^T (*) x in one call (split-K main kernel + fixed-order reduction)."""
-    _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
-    _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
+    _chk_conv(dy, (g.N, g.Ho, g.Wo, g.Cout), g, 'dy')
+    _chk_conv(x, (g.N, g.H, g.W, g.Cin), g, 'x')
     if dw is None:
         dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
         beta = 0.0
@@ -442,6 +476,27 @@ def bn_relu_maxpool_fwd(y, scale, shift):
     return out, idx, mask
 
 
+def maxpool_t2_fwd(x):
+    """MaxPool3d((2,1,1),(2,1,1)) on frames (2n, H, W, C) -> ((n, H, W, C), sel bit mask)."""
+    _chk(x, name='x')
+    N2, H, W, C = x.shape
+    if N2 % 2 or (H * W * C) % 32:
+        raise ValueError(f'maxpool_t2_fwd: {tuple(x.shape)}: needs an even frame count and H*W*C % 32 == 0')
+    out = torch.empty((N2 // 2, H, W, C), dtype=torch.float32, device=x.device)
+    sel = torch.empty(out.numel() // 32, dtype=torch.int32, device=x.device)
+    check(lib().bdv_maxpool_t2_fwd(_p(x), _p(out), _p(sel), N2 // 2, H * W * C, _stream()), 'bdv_maxpool_t2_fwd')
+    return out, sel
+
+
+def maxpool_t2_bwd(dout, sel):
+    _chk(dout, name='dout')
+    n, H, W, C = dout.shape
+    _chk(sel, (dout.numel() // 32,), dtype=torch.int32, name='sel')
+    dx = torch.empty((2 * n, H, W, C), dtype=torch.float32, device=dout.device)
+    check(lib().bdv_maxpool_t2_bwd(_p(dout), _p(sel), _p(dx), n, H * W * C, _stream()), 'bdv_maxpool_t2_bwd')
+    return dx
+
+
 def maxpool_bwd(dout, idx, in_shape):
     N, H, W, C = in_shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -518,8 +573,8 @@ def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, x3: Optio
                        dw: Optional[torch.Tensor] = None):
     """Split-K partial products of a weight gradient -> (slab (splits, Cout, R, S, Cin), empty dw); reduce them later with
     ``wgrad_reduce_batched`` (the slab must stay alive until then)."""
-    _chk(dy, (g.N, g.Ho, g.Wo, g.Cout), name='dy')
-    _chk(x, (g.N, g.H, g.W, g.Cin), name='x')
+    _chk_conv(dy, (g.N, g.Ho, g.Wo, g.Cout), g, 'dy')
+    _chk_conv(x, (g.N, g.H, g.W, g.Cin), g, 'x')
     use_x3 = WGRAD_X3 if x3 is None else x3
     use_pl = use_x3 and USE_PL_WGRAD
     splits = (lib().bdv_conv_wgrad_pl_splits if use_pl else lib().bdv_conv_wgrad_splits)(ctypes.byref(g))

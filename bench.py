@@ -64,20 +64,7 @@ class ConvTimer:
         timer = self
 
         def kernel_tag(kind, g, x3):
-            if kind == 'fprop':
-                if g.Cin == 4:
-                    return 'conv_fprop_c4_kernel<128,64,2,2>'
-                if g.Cout % 128 == 0:
-                    return 'conv_fprop_x3_kernel<128,128,2,2>' if x3 else 'conv_fprop_kernel<128,128,2,2>'
-                return 'conv_fprop_kernel<128,64,2,2>'
-            if kind == 'dgrad':
-                if g.Cin % 128 == 0:
-                    return 'conv_dgrad_x3_kernel<128,128,2,2>' if x3 else 'conv_dgrad_kernel<128,128,2,2>'
-                return 'conv_dgrad_kernel<128,64,2,2>'
-            small = (g.Cin % 32 != 0) or (g.Cout % 128 != 0) or (g.Cin % 128 != 0)
-            if small:
-                return 'conv_wgrad_kernel<64,64,2,2>'
-            return 'conv_wgrad_x3_kernel<128,128,2,2>' if x3 else 'conv_wgrad_kernel<128,128,2,2>'
+            return K.conv_kernel_name(g, kind, x3).replace(' ', '')
 
         def make(kind, fn, geom_pos, flag):
             def timed(*a, **kw):
@@ -142,12 +129,14 @@ def pmc_traffic(tag):
         return None
     with open(path) as f:
         kernels = json.load(f).get('kernels', {})
-    want = tag.replace(' ', '')
+    base = tag.replace(' ', '').rstrip('>')                # a tag may stop before trailing template flags (wgrad: INCR)
+    tot, launches = 0.0, 0
     for name, v in kernels.items():
         n = name.replace(' ', '')
-        if n == want or n.startswith(want[:-1] + ','):      # wgrad carries two more template flags
-            return v.get('hbm_bytes_per_launch')
-    return None
+        if n.startswith(base) and n[len(base):len(base) + 1] in ('>', ','):
+            tot += (v.get('hbm_bytes_per_launch') or 0) * v.get('launches', 1)
+            launches += v.get('launches', 1)
+    return round(tot / launches) if launches else None
 
 
 def rocprof_avg_us(tag):
@@ -157,13 +146,13 @@ def rocprof_avg_us(tag):
     path = os.path.join(ROOT, 'profiles', f'{PROFILE_ROUND}_kernel_stats.csv')
     if not os.path.exists(path):
         return None
-    want = tag.replace(' ', '')
+    base = tag.replace(' ', '').rstrip('>')
     tot_ns, calls = 0.0, 0
     with open(path) as f:
         for row in csv.DictReader(f):
             n = row['Name'].replace(' ', '')
-            k = n.find(want[:-1])
-            if k >= 0 and n[k + len(want) - 1] in '>,':
+            k = n.find(base)
+            if k >= 0 and n[k + len(base):k + len(base) + 1] in ('>', ','):
                 tot_ns += float(row['TotalDurationNs'])
                 calls += int(row['Calls'])
     return round(tot_ns / calls / 1e3, 2) if calls else None
@@ -398,7 +387,8 @@ def main():
             conv = {k: v for k, v in by.items() if v['flops'] > 0}
             dom = max(conv, key=lambda k: conv[k]['ms'])
             d = conv[dom]
-            peak = PEAK_BF16X3 if '_x3_' in dom else PEAK_F32_MFMA
+            bf16_pieces = '_x3_' in dom or '_pl_' in dom
+            peak = PEAK_BF16X3 if bf16_pieces else PEAK_F32_MFMA
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
             tot_ms = sum(v['ms'] for v in by.values())
             tot_fl = sum(v['flops'] for v in by.values())
@@ -406,7 +396,7 @@ def main():
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak / 1e12, 1), 'unit': 'TFLOP/s',
                 'frac': round(achieved * 1e12 / peak, 4), 'traffic': pmc_traffic(dom),
                 'peak_note': ('fp32-equivalent FLOP (2*M*N*K) against the bf16 dense MFMA peak / 6: every fp32 product costs six '
-                              'v_mfma_f32_32x32x16_bf16 products' if '_x3_' in dom else 'v_mfma_f32_32x32x2_f32 dense peak'),
+                              'v_mfma_f32_32x32x16_bf16 products' if bf16_pieces else 'v_mfma_f32_32x32x2_f32 dense peak'),
                 'frac_of_f32_mfma_peak': round(achieved * 1e12 / PEAK_F32_MFMA, 4),
                 'traffic_note': f'HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of '
                                 f'this command, profiles/{PROFILE_ROUND}_traffic.json); avg_launch_ms spans the whole C-ABI call '

@@ -43,6 +43,10 @@ typedef struct bdv_conv_geom {
   int32_t pad;
   int32_t T;      /* num_segments (frames per clip); used only when fold > 0 */
   int32_t fold;   /* temporal-shift fold = Cin / shift_div, multiple of 4; 0 = no shift */
+  int32_t pad_w;  /* column padding when it differs from `pad` (then `pad` pads rows only); < 0: same as `pad`.
+                   * A k x 1 x 1 temporal convolution of an I3D block (UPSTREAM mmaction ResNet3d Bottleneck3d.conv1,
+                   * configs/_base_/models/i3d_r50.py:13) runs as a k x 1 conv on the [B][T][H*W][C] view of the same NHWC
+                   * storage: N = B, H = T, W = H*W, R = k, S = 1, pad = k / 2, pad_w = 0. */
 } bdv_conv_geom;
 
 const char* bdv_last_error(void);
@@ -127,6 +131,9 @@ int bdv_conv_debug_force_tile(int cfg);
 /* 1 when bdv_conv_fprop_pl (kind 0) / bdv_conv_dgrad_pl (kind 1) will read the weight planes for this geometry, 0 when it
  * runs a kernel that takes w (the caller then need not build the planes). */
 int bdv_conv_uses_planes(const bdv_conv_geom* g, int kind);
+/* Name of the main kernel that a call with this geometry launches, as a profiler prints it (kind 0 fprop, 1 dgrad, 2 wgrad;
+ * arith 0 = the fp32-MFMA entry points, 1 = the *_pl entry points).  For profiles and per-kernel accounting. */
+int bdv_conv_kernel_name(const bdv_conv_geom* g, int kind, int arith, char* out, size_t n);
 int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* g);
 int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* g);
 int bdv_conv_fprop_pl(const float* x, const float* w, const void* planes_fprop, float* y, const bdv_conv_geom* g,
@@ -209,6 +216,11 @@ int bdv_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* st
  * per output element (first maximum in scan order, as torch). */
 int bdv_maxpool_fwd(const float* x, float* out, uint8_t* idx, int N, int H, int W, int C, void* stream);
 int bdv_maxpool_bwd(const float* dout, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream);
+/* MaxPool3d((2,1,1), stride (2,1,1)) -- pool2 of UPSTREAM mmaction ResNet3d (I3D, configs/_base_/models/i3d_r50.py:1-27): the
+ * element-wise larger of frames 2t and 2t+1 of x [2*frames_out][frame_elems] (frame_elems % 32 == 0; an even number of frames
+ * per clip keeps pairs inside a clip).  sel: 1 bit per output element (second frame won); the backward fills dx completely. */
+int bdv_maxpool_t2_fwd(const float* x, float* out, uint32_t* sel, int64_t frames_out, int64_t frame_elems, void* stream);
+int bdv_maxpool_t2_bwd(const float* dout, const uint32_t* sel, float* dx, int64_t frames_out, int64_t frame_elems, void* stream);
 /* Stem tail of a training forward in one pass (UPSTREAM ConvModule norm+act, then ResNet.maxpool): a = relu(y * scale +
  * shift), out = maxpool(a), idx as bdv_maxpool_fwd, relu_mask = 1 bit per element of a (a > 0) as bdv_bn_apply writes it.
  * The activation a itself is not materialised. */
