@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _lib = None
 
@@ -55,18 +55,18 @@ SIGNATURES = {
     'bdv_conv_weight_planes_bytes': (c_size_t, [POINTER(ConvGeom)]),
     'bdv_conv_split_weights': (c_int, [P, POINTER(ConvGeom), P, P, P]),
     'bdv_conv_debug_force_tile': (c_int, [c_int]),
-    'bdv_conv_uses_planes': (c_int, [POINTER(ConvGeom), c_int]),
+    'bdv_conv_uses_planes': (c_int, [POINTER(ConvGeom), c_int, c_int]),
     'bdv_conv_kernel_name': (c_int, [POINTER(ConvGeom), c_int, c_int, c_char_p, c_size_t]),
-    'bdv_conv_fprop_pl_stat_rows': (c_int, [POINTER(ConvGeom)]),
-    'bdv_conv_dgrad_pl_stat_rows': (c_int, [POINTER(ConvGeom)]),
-    'bdv_conv_fprop_pl': (c_int, [P, P, P, P, POINTER(ConvGeom), P, POINTER(ConvAffine), P, c_size_t, P]),
-    'bdv_conv_dgrad_pl': (c_int, [P, P, P, P, P, P, POINTER(ConvGeom), POINTER(BnStatFuse), P, c_size_t, P]),
+    'bdv_conv_fprop_pl_stat_rows': (c_int, [POINTER(ConvGeom), c_int]),
+    'bdv_conv_dgrad_pl_stat_rows': (c_int, [POINTER(ConvGeom), c_int]),
+    'bdv_conv_fprop_pl': (c_int, [P, P, P, P, POINTER(ConvGeom), P, POINTER(ConvAffine), P, c_size_t, c_int, P]),
+    'bdv_conv_dgrad_pl': (c_int, [P, P, P, P, P, P, POINTER(ConvGeom), POINTER(BnStatFuse), P, c_size_t, c_int, P]),
     'bdv_conv_wgrad': (c_int, [P, P, P, c_float, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_conv_wgrad_splits': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_wgrad_partial': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_conv_wgrad_partial_x3': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_conv_wgrad_pl_splits': (c_int, [POINTER(ConvGeom)]),
-    'bdv_conv_wgrad_partial_pl': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, P]),
+    'bdv_conv_wgrad_partial_pl': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, c_int, P]),
     'bdv_wgrad_reduce_batched': (c_int, [P, P, P, P, c_int, c_float, P]),
     'bdv_bn_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'bdv_bn_train_stats': (c_int, [P, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_size_t, P]),

@@ -13,4 +13,4 @@ void bdv_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* bdv_last_error(void) { return g_err; }
-extern "C" int bdv_abi_version(void) { return 22; }
+extern "C" int bdv_abi_version(void) { return 23; }

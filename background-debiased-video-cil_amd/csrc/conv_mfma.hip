@@ -1760,16 +1760,18 @@ __device__ __forceinline__ int pl_frag_off(int row0, int s, int lane) {
   return pl_off(row0 + r, 2 * s + h);
 }
 
-template <int BM, int BN, int WM, int WN>
+// NP = 3: the six piece products (fp32-level result).  NP = 1: only the leading bf16 piece of each operand, one MFMA product
+// per step -- the reduced-precision arithmetic of BASELINE config 5 (bf16 operands, fp32 accumulate), see bdv_conv_fprop_pl.
+template <int BM, int BN, int WM, int WN, int NP = 3>
 __device__ __forceinline__ void mma_stage_pl(const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs,
                                              f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const int (&fa)[2], const int (&fb)[2]) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int PA = BM * 64, PB = BN * 64;
 #pragma unroll
   for (int s = 0; s < BK / 16; ++s) {
-    bf16x8_t a[3][TM], b[3][TN];
+    bf16x8_t a[NP][TM], b[NP][TN];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[p][i] = *reinterpret_cast<const bf16x8_t*>(As + fa[s] + (p * PA + 32 * WM * i * 64));
 #pragma unroll
@@ -1779,20 +1781,27 @@ __device__ __forceinline__ void mma_stage_pl(const unsigned char* __restrict__ A
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {  // smallest terms first
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+        if constexpr (NP == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+        }
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
       }
   }
 }
 
-// fp32 x 4 -> the three planes of a stage image at the thread's precomputed byte offset `off` (+ a constant row offset)
+// fp32 x 4 -> the three planes (NP = 1: the leading one) of a stage image at the thread's precomputed byte offset
+template <int NP = 3>
 __device__ __forceinline__ void pl_split_store_at(unsigned char* __restrict__ q, int plane_bytes, const float4 v) {
   const f32x4_t a = {v.x, v.y, v.z, v.w};
   const bf16x4_t hi = __builtin_convertvector(a, bf16x4_t);
+  if constexpr (NP == 1) {
+    *reinterpret_cast<bf16x4_t*>(q) = hi;
+    return;
+  }
   const f32x4_t r1 = a - __builtin_convertvector(hi, f32x4_t);
   const bf16x4_t mid = __builtin_convertvector(r1, bf16x4_t);
   const f32x4_t r2 = r1 - __builtin_convertvector(mid, f32x4_t);
@@ -1845,7 +1854,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 }
 
 // ---- fprop ------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NBUF>
+template <int BM, int BN, int WM, int WN, int NBUF, int NP = 3>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_kernel(const float* __restrict__ x,
                                                                                       const unsigned short* __restrict__ wp,
                                                                                       float* __restrict__ y, Geom g, int NT, Work wk,
@@ -1903,7 +1912,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
   }
 
   float4 ra[AP];
-  u32x4 rb[3 * BPP];
+  u32x4 rb[NP * BPP];
   auto load = [&]() {
     const int cls = shift_class(chunk * BK + 4 * kg, g.fold);
     const int koff_a = ((r * g.W + s) * g.Cin + chunk * BK) * 4;
@@ -1915,7 +1924,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
       ra[p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB), 0);
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
       for (int q = 0; q < BPP; ++q) rb[pl * BPP + q] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_base[q] + pl * plane_bytes, koff_b, 0);
     kt_w += 1;
@@ -1935,10 +1944,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
     unsigned char* const As = smem_b + stage * STAGE;
     unsigned char* const Bs = As + 3 * PA;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) pl_split_store_at(As + st_a + (NTHR / 8) * p * 64, PA, ra[p]);
+    for (int p = 0; p < AP; ++p) pl_split_store_at<NP>(As + st_a + (NTHR / 8) * p * 64, PA, ra[p]);
     if (b_active) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
         for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + st_b + (pl * PB + (NTHR / 4) * q * 64)) = rb[pl * BPP + q];
     }
@@ -1953,12 +1962,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
     if (kt + 1 < it.ke) load();
     __syncthreads();
     while (true) {
-      mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
+      mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + 3 * PA, acc, fa, fb);
       if (kt + 1 < it.ke) store(1);
       if (kt + 2 < it.ke) load();
       __syncthreads();
       if (++kt >= it.ke) break;
-      mma_stage_pl<BM, BN, WM, WN>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, fa, fb);
+      mma_stage_pl<BM, BN, WM, WN, NP>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, fa, fb);
       if (kt + 1 < it.ke) store(0);
       if (kt + 2 < it.ke) load();
       __syncthreads();
@@ -1971,7 +1980,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
       store(0);
       __syncthreads();
       if (kt + 1 < it.ke) load();
-      mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
+      mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + 3 * PA, acc, fa, fb);
     }
   }
 
@@ -1984,7 +1993,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
 
 // ---- dgrad ------------------------------------------------------------------------------------
 // dp = the D planes of bdv_conv_split_weights: B rows = input channels ci, contraction over (tap, co) with co contiguous.
-template <int BM, int BN, int WM, int WN, int NBUF>
+template <int BM, int BN, int WM, int WN, int NBUF, int NP = 3>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_kernel(const float* __restrict__ dy,
                                                                                       const unsigned short* __restrict__ dp,
                                                                                       float* __restrict__ dx,
@@ -2071,7 +2080,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
   const int nchunk = g.Cout / BK;
 
   float4 ra[AP];
-  u32x4 rb[3 * BPP];
+  u32x4 rb[NP * BPP];
   auto load = [&]() {
     const int tap = (r0 + ir * st) * g.S + (s0 + is * st);
     const int koff_a = (chunk * BK - (ir * g.Wo + is) * g.Cout) * 4;
@@ -2082,7 +2091,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
       ra[p] = buf_load16(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB), 0);
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
       for (int q = 0; q < BPP; ++q) rb[pl * BPP + q] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_base[q] + pl * plane_bytes, koff_b, 0);
     is += 1;
@@ -2101,10 +2110,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
     unsigned char* const As = smem_b + stage * STAGE;
     unsigned char* const Bs = As + 3 * PA;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) pl_split_store_at(As + st_a + (NTHR / 8) * p * 64, PA, ra[p]);
+    for (int p = 0; p < AP; ++p) pl_split_store_at<NP>(As + st_a + (NTHR / 8) * p * 64, PA, ra[p]);
     if (b_active) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
         for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + st_b + (pl * PB + (NTHR / 4) * q * 64)) = rb[pl * BPP + q];
     }
@@ -2121,12 +2130,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
       if (kt + 1 < it.ke) load();
       __syncthreads();
       while (true) {
-        mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
+        mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + 3 * PA, acc, fa, fb);
         if (kt + 1 < it.ke) store(1);
         if (kt + 2 < it.ke) load();
         __syncthreads();
         if (++kt >= it.ke) break;
-        mma_stage_pl<BM, BN, WM, WN>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, fa, fb);
+        mma_stage_pl<BM, BN, WM, WN, NP>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, fa, fb);
         if (kt + 1 < it.ke) store(0);
         if (kt + 2 < it.ke) load();
         __syncthreads();
@@ -2139,7 +2148,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
         store(0);
         __syncthreads();
         if (kt + 1 < it.ke) load();
-        mma_stage_pl<BM, BN, WM, WN>(smem_b, smem_b + 3 * PA, acc, fa, fb);
+        mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + 3 * PA, acc, fa, fb);
       }
     }
   }
@@ -2166,11 +2175,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
 // Eight waves (2 x 4), one workgroup per CU, one LDS stage.
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
-template <int COLS>
+template <int COLS, int NP = 3>
 __device__ __forceinline__ void pl_store_rows(unsigned char* __restrict__ base, int krow, int c4, const float4 v) {
   constexpr int PITCH = 2 * COLS + 64, PLANE = 32 * PITCH;
   const f32x4_t a = {v.x, v.y, v.z, v.w};
   const bf16x4_t hi = __builtin_convertvector(a, bf16x4_t);
+  if constexpr (NP == 1) {
+    *reinterpret_cast<bf16x4_t*>(base + krow * PITCH + 8 * c4) = hi;
+    return;
+  }
   const f32x4_t r1 = a - __builtin_convertvector(hi, f32x4_t);
   const bf16x4_t mid = __builtin_convertvector(r1, bf16x4_t);
   const f32x4_t r2 = r1 - __builtin_convertvector(mid, f32x4_t);
@@ -2195,7 +2208,7 @@ __device__ __forceinline__ bf16x8_t pl_frag_tr(const unsigned char* __restrict__
   return __builtin_bit_cast(bf16x8_t, f);
 }
 
-template <int BM, int BN, bool INCR>
+template <int BM, int BN, bool INCR, int NP = 3>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_pl_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 float* __restrict__ slab, Geom g, int MTw, int NTw,
                                                                 int kt_per_split) {
@@ -2322,16 +2335,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pl_kernel(const float* __re
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       __syncthreads();
 #pragma unroll
-      for (int p = 0; p < AP; ++p) pl_store_rows<BM>(As, a_krow[p], (tid + NTHR * p) % AV, ra[p]);
+      for (int p = 0; p < AP; ++p) pl_store_rows<BM, NP>(As, a_krow[p], (tid + NTHR * p) % AV, ra[p]);
 #pragma unroll
-      for (int p = 0; p < BP; ++p) pl_store_rows<BN>(Bs, b_krow[p], (tid + NTHR * p) % BV, rb[p]);
+      for (int p = 0; p < BP; ++p) pl_store_rows<BN, NP>(Bs, b_krow[p], (tid + NTHR * p) % BV, rb[p]);
       __syncthreads();
       if (kt + 1 < kt_end) load(kt + 1);
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
-        bf16x8_t a[3][TM], b[3][TN];
+        bf16x8_t a[NP][TM], b[NP][TN];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) a[p][i] = pl_frag_tr<BM>(As + p * PLANE_A, 32 * WM * i + 32 * wm, s, lane);
 #pragma unroll
@@ -2341,11 +2354,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pl_kernel(const float* __re
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+            if constexpr (NP == 3) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+            }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
           }
       }
@@ -2568,8 +2583,11 @@ int pl_tile_override() {
 //     and for stride-2 3x3 filters (four parity classes with a quarter of the taps each).
 // Returns the tile configuration, or -1 for the kernels that take fp32 weights.  BDVCIL_PL_TILE / bdv_conv_debug_force_tile
 // override the rules wherever the forced tile divides the column count.
-int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride) {
+int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride, int pieces = 3) {
   const int forced = pl_tile_override();
+  if (pieces == 1)  // the single-product arithmetic only exists in the 8-wave kernels
+    return forced >= 0 && forced < kNumPlCfg && ncols % kPlCfg[forced].BN == 0 ? forced
+           : ncols % 256 == 0 ? 0 : ncols % 128 == 0 ? 1 : ncols % 64 == 0 ? 3 : -1;
   if (forced == kNumPlCfg) return -1;  // "none": the kernels of the other family everywhere
   if (forced >= 0 && ncols % kPlCfg[forced].BN == 0) return forced;
   if (ncols % 64 != 0) return -1;
@@ -2615,16 +2633,16 @@ bool r1_planes_enabled() {
   return on;
 }
 
-int pl_fprop_cfg(const bdv_conv_geom* g) {
+int pl_fprop_cfg(const bdv_conv_geom* g, int pieces = 3) {
   if (g->Cin % BK != 0) return -1;
-  return pl_pick(false, g->Cout, g->R * g->S * g->Cin / BK, g->R * g->S, g->stride);
+  return pl_pick(false, g->Cout, g->R * g->S * g->Cin / BK, g->R * g->S, g->stride, pieces);
 }
-int pl_dgrad_cfg(const bdv_conv_geom* g) {
+int pl_dgrad_cfg(const bdv_conv_geom* g, int pieces = 3) {
   if (g->Cout % BK != 0) return -1;
-  return pl_pick(true, g->Cin, g->R * g->S * g->Cout / BK, g->R * g->S, g->stride);
+  return pl_pick(true, g->Cin, g->R * g->S * g->Cout / BK, g->R * g->S, g->stride, pieces);
 }
-bool pl_fprop_ok(const bdv_conv_geom* g) { return pl_fprop_cfg(g) >= 0; }
-bool pl_dgrad_ok(const bdv_conv_geom* g) { return pl_dgrad_cfg(g) >= 0; }
+bool pl_fprop_ok(const bdv_conv_geom* g, int pieces = 3) { return pl_fprop_cfg(g, pieces) >= 0; }
+bool pl_dgrad_ok(const bdv_conv_geom* g, int pieces = 3) { return pl_dgrad_cfg(g, pieces) >= 0; }
 
 
 struct WgradPlan {
@@ -2732,14 +2750,16 @@ extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
   }
   size_t need = p.wk.split > 1 ? (size_t)p.wk.rem_tiles * p.wk.split * p.seg_bytes : 0;
   // the P kernels (bdv_conv_fprop_pl / bdv_conv_dgrad_pl) plan their own K-split
-  if (kind == 0 && pl_fprop_ok(gg)) {
-    const PlPlan q = plan_pl(pl_fprop_cfg(gg), g.M, g.Cout, g.Ktot / BK, kMaxSplitWorkspace, true);
-    const size_t n2 = q.wk.split > 1 ? (size_t)q.wk.rem_tiles * q.wk.split * q.seg_bytes : 0;
-    need = n2 > need ? n2 : need;
-  } else if (kind == 1 && pl_dgrad_ok(gg) && gg->stride == 1) {
-    const PlPlan q = plan_pl(pl_dgrad_cfg(gg), g.M, g.Cin, g.Ktot / BK, kMaxSplitWorkspace, true);
-    const size_t n2 = q.wk.split > 1 ? (size_t)q.wk.rem_tiles * q.wk.split * q.seg_bytes : 0;
-    need = n2 > need ? n2 : need;
+  for (int pieces = 1; pieces <= 3; pieces += 2) {
+    if (kind == 0 && pl_fprop_ok(gg, pieces)) {
+      const PlPlan q = plan_pl(pl_fprop_cfg(gg, pieces), g.M, g.Cout, g.Ktot / BK, kMaxSplitWorkspace, true);
+      const size_t n2 = q.wk.split > 1 ? (size_t)q.wk.rem_tiles * q.wk.split * q.seg_bytes : 0;
+      need = n2 > need ? n2 : need;
+    } else if (kind == 1 && pl_dgrad_ok(gg, pieces) && gg->stride == 1) {
+      const PlPlan q = plan_pl(pl_dgrad_cfg(gg, pieces), g.M, g.Cin, g.Ktot / BK, kMaxSplitWorkspace, true);
+      const size_t n2 = q.wk.split > 1 ? (size_t)q.wk.rem_tiles * q.wk.split * q.seg_bytes : 0;
+      need = n2 > need ? n2 : need;
+    }
   }
   return need > 16 ? need : 16;
 }
@@ -2912,16 +2932,16 @@ extern "C" int bdv_conv_debug_force_tile(int cfg) {
 
 // Name of the main kernel a call will launch (as rocprofv3 prints it, without the anonymous namespace): for profiles and
 // bench.py's per-kernel accounting.  kind 0 = fprop, 1 = dgrad, 2 = wgrad; arith 0 = fp32 MFMA entry points, 1 = the default
-// bf16-piece entry points (bdv_conv_fprop_pl / bdv_conv_dgrad_pl / bdv_conv_wgrad_partial_pl).
+// bf16-piece entry points (bdv_conv_fprop_pl / bdv_conv_dgrad_pl / bdv_conv_wgrad_partial_pl), 2 = the same with pieces = 1.
 extern "C" int bdv_conv_kernel_name(const bdv_conv_geom* gg, int kind, int arith, char* out, size_t n) {
   if (int e = check_geom(gg, "bdv_conv_kernel_name")) return e;
   BDV_REQUIRE(out && n > 0 && kind >= 0 && kind <= 2, "bdv_conv_kernel_name: bad argument");
   const bool c4 = gg->Cin % BK != 0;
   if (kind == 0) {
-    const int cfg = arith ? pl_fprop_cfg(gg) : -1;
+    const int cfg = arith ? pl_fprop_cfg(gg, arith == 2 ? 1 : 3) : -1;
     if (cfg >= 0) {
       const int wm = cfg == 0 || cfg == 2 ? 2 : 4;
-      snprintf(out, n, "conv_fprop_pl_kernel<%d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, wm, 8 / wm, kPlCfg[cfg].nbuf);
+      snprintf(out, n, "conv_fprop_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, wm, 8 / wm, kPlCfg[cfg].nbuf, arith == 2 ? 1 : 3);
     } else if (c4) {
       snprintf(out, n, "conv_fprop_c4_kernel<128, %d, 2, 2>", gg->Cout % 128 == 0 ? 128 : 64);
     } else if (gg->Cout % 128 == 0 && arith) {
@@ -2930,10 +2950,10 @@ extern "C" int bdv_conv_kernel_name(const bdv_conv_geom* gg, int kind, int arith
       snprintf(out, n, "conv_fprop_kernel<128, %d, 2, 2>", gg->Cout % 128 == 0 ? 128 : 64);
     }
   } else if (kind == 1) {
-    const int cfg = arith ? pl_dgrad_cfg(gg) : -1;
+    const int cfg = arith ? pl_dgrad_cfg(gg, arith == 2 ? 1 : 3) : -1;
     if (cfg >= 0) {
       const int wm = cfg == 0 || cfg == 2 ? 2 : 4;
-      snprintf(out, n, "conv_dgrad_pl_kernel<%d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, wm, 8 / wm, kPlCfg[cfg].nbuf);
+      snprintf(out, n, "conv_dgrad_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, wm, 8 / wm, kPlCfg[cfg].nbuf, arith == 2 ? 1 : 3);
     } else if (gg->Cin % 128 == 0 && arith) {
       snprintf(out, n, "conv_dgrad_x3_kernel<128, 128, 2, 2, %s>", r1_planes_enabled() ? "true" : "false");
     } else {
@@ -2951,24 +2971,24 @@ extern "C" int bdv_conv_kernel_name(const bdv_conv_geom* gg, int kind, int arith
   return BDV_OK;
 }
 
-extern "C" int bdv_conv_uses_planes(const bdv_conv_geom* gg, int kind) {
+extern "C" int bdv_conv_uses_planes(const bdv_conv_geom* gg, int kind, int pieces) {
   if (check_geom(gg, "bdv_conv_uses_planes")) return 0;
-  if (kind == 0) return pl_fprop_ok(gg) || (r1_planes_enabled() && gg->Cin % BK == 0 && gg->Cout % 128 == 0) ? 1 : 0;
-  if (kind == 1) return pl_dgrad_ok(gg) || (r1_planes_enabled() && gg->Cout % BK == 0 && gg->Cin % 128 == 0) ? 1 : 0;
+  if (kind == 0) return pl_fprop_ok(gg, pieces) || (pieces == 3 && r1_planes_enabled() && gg->Cin % BK == 0 && gg->Cout % 128 == 0) ? 1 : 0;
+  if (kind == 1) return pl_dgrad_ok(gg, pieces) || (pieces == 3 && r1_planes_enabled() && gg->Cout % BK == 0 && gg->Cin % 128 == 0) ? 1 : 0;
   return 0;
 }
 
-extern "C" int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* gg) {
+extern "C" int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* gg, int pieces) {
   if (check_geom(gg, "bdv_conv_fprop_pl_stat_rows")) return 0;
-  if (!pl_fprop_ok(gg)) return bdv_conv_fprop_stat_rows(gg);
-  const PlPlan p = plan_pl(pl_fprop_cfg(gg), gg->N * gg->Ho * gg->Wo, gg->Cout, gg->R * gg->S * gg->Cin / BK, kMaxSplitWorkspace, true);
+  if (!pl_fprop_ok(gg, pieces)) return bdv_conv_fprop_stat_rows(gg);
+  const PlPlan p = plan_pl(pl_fprop_cfg(gg, pieces), gg->N * gg->Ho * gg->Wo, gg->Cout, gg->R * gg->S * gg->Cin / BK, kMaxSplitWorkspace, true);
   return p.cfg >= 0 ? p.MT : 0;
 }
 
-extern "C" int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* gg) {
+extern "C" int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* gg, int pieces) {
   if (check_geom(gg, "bdv_conv_dgrad_pl_stat_rows")) return 0;
-  if (!pl_dgrad_ok(gg) || gg->stride != 1) return bdv_conv_dgrad_stat_rows(gg);
-  const PlPlan p = plan_pl(pl_dgrad_cfg(gg), gg->N * gg->H * gg->W, gg->Cin, gg->R * gg->S * gg->Cout / BK, kMaxSplitWorkspace, true);
+  if (!pl_dgrad_ok(gg, pieces) || gg->stride != 1) return bdv_conv_dgrad_stat_rows(gg);
+  const PlPlan p = plan_pl(pl_dgrad_cfg(gg, pieces), gg->N * gg->H * gg->W, gg->Cin, gg->R * gg->S * gg->Cout / BK, kMaxSplitWorkspace, true);
   return p.cfg >= 0 ? p.MT : 0;
 }
 
@@ -2986,9 +3006,10 @@ extern "C" int bdv_conv_split_weights(const float* w, const bdv_conv_geom* gg, v
 
 extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* planes_fprop, float* y, const bdv_conv_geom* gg,
                                  float* bn_partial, const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+                                 int pieces, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_fprop_pl")) return e;
-  if (planes_fprop == nullptr || !pl_fprop_ok(gg))  // sites of the two-workgroups-per-CU kernels (weights from the planes too)
+  BDV_REQUIRE(pieces == 3 || pieces == 1, "bdv_conv_fprop_pl: pieces = %d (3 or 1)", pieces);
+  if (planes_fprop == nullptr || !pl_fprop_ok(gg, pieces))  // sites of the two-workgroups-per-CU kernels (weights from the planes too)
     return conv_fprop_impl(x, w, y, gg, bn_partial, affine, workspace, workspace_bytes, stream, true,
                            gg->Cin % BK == 0 && r1_planes_enabled() ? planes_fprop : nullptr);
   BDV_REQUIRE(x && y, "bdv_conv_fprop_pl: null pointer");
@@ -3010,7 +3031,7 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
   g.Ktot = g.R * g.S * g.Cin;
   BDV_REQUIRE((int64_t)3 * g.Cout * g.Ktot * 2 < (1ll << 31), "bdv_conv_fprop_pl: weight planes exceed 2^31 bytes");
   hipStream_t s = (hipStream_t)stream;
-  const PlPlan p = plan_pl(pl_fprop_cfg(gg), g.M, g.Cout, g.Ktot / BK, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, true);
+  const PlPlan p = plan_pl(pl_fprop_cfg(gg, pieces), g.M, g.Cout, g.Ktot / BK, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, true);
   BDV_REQUIRE(p.cfg >= 0, "bdv_conv_fprop_pl: no tile configuration for Cout=%d", g.Cout);
   // bn_partial has one row per row tile of THIS kernel: bdv_conv_fprop_pl_stat_rows(g)
   const int blocks = p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split;
@@ -3022,8 +3043,12 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
             g.W, g.Cin, g.Cout, g.R, g.stride, p.cfg, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split, p.est_us);
 #define BDV_FPROP_PL(BM_, BN_, WM_, WN_, NB_)                                                                                         \
   do {                                                                                                                                \
-    hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y, g, p.NT,   \
-                       p.wk, slab, epi);                                                                                              \
+    if (pieces == 1)                                                                                                                  \
+      hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_, 1>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y, g,    \
+                         p.NT, p.wk, slab, epi);                                                                                      \
+    else                                                                                                                              \
+      hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_, 3>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y, g,    \
+                         p.NT, p.wk, slab, epi);                                                                                      \
     BDV_LAUNCH_CHECK("bdv_conv_fprop_pl");                                                                                            \
     if (p.wk.split > 1) {                                                                                                             \
       hipLaunchKernelGGL((conv_fprop_fixup_kernel<BM_, BN_, WM_, WN_>), dim3(p.wk.rem_tiles), dim3(64 * WM_ * WN_), 0, s,             \
@@ -3041,9 +3066,10 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
 
 extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* planes_dgrad, float* dx, const float* add_src,
                                  const uint32_t* add_mask_src, const bdv_conv_geom* gg, const bdv_bn_stat_fuse* bn_stat,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+                                 void* workspace, size_t workspace_bytes, int pieces, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_dgrad_pl")) return e;
-  if (planes_dgrad == nullptr || !pl_dgrad_ok(gg))
+  BDV_REQUIRE(pieces == 3 || pieces == 1, "bdv_conv_dgrad_pl: pieces = %d (3 or 1)", pieces);
+  if (planes_dgrad == nullptr || !pl_dgrad_ok(gg, pieces))
     return conv_dgrad_impl(dy, w, nullptr, dx, add_src, add_mask_src, gg, bn_stat, workspace, workspace_bytes, stream,
                            gg->Cout % BK == 0 && r1_planes_enabled() ? planes_dgrad : nullptr);
   BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
@@ -3070,7 +3096,7 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
   hipStream_t s = (hipStream_t)stream;
   const int st = g.stride;
   const int Mc0 = g.N * ((g.H + st - 1) / st) * ((g.W + st - 1) / st);  // largest parity class
-  PlPlan p = plan_pl(pl_dgrad_cfg(gg), st == 1 ? g.M : Mc0, g.Cin, g.Ktot / BK,
+  PlPlan p = plan_pl(pl_dgrad_cfg(gg, pieces), st == 1 ? g.M : Mc0, g.Cin, g.Ktot / BK,
                      workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, st == 1);
   BDV_REQUIRE(p.cfg >= 0, "bdv_conv_dgrad_pl: no tile configuration for Cin=%d", g.Cin);
   if (st != 1) p.wk.dp_tiles = ((p.MT + 7) / 8) * 8 * p.NT;  // padded grid per parity class
@@ -3085,8 +3111,12 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
             g.W, g.Cin, g.Cout, g.R, g.stride, p.cfg, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split, p.est_us);
 #define BDV_DGRAD_PL(BM_, BN_, WM_, WN_, NB_)                                                                                          \
   do {                                                                                                                                 \
-    hipLaunchKernelGGL((conv_dgrad_pl_kernel<BM_, BN_, WM_, WN_, NB_>), grid, dim3(64 * WM_ * WN_), 0, s, dy, dp, dx, add_src,          \
-                       add_mask_src, g, p.NT, p.wk, slab, stat);                                                                       \
+    if (pieces == 1)                                                                                                                   \
+      hipLaunchKernelGGL((conv_dgrad_pl_kernel<BM_, BN_, WM_, WN_, NB_, 1>), grid, dim3(64 * WM_ * WN_), 0, s, dy, dp, dx, add_src,     \
+                         add_mask_src, g, p.NT, p.wk, slab, stat);                                                                     \
+    else                                                                                                                               \
+      hipLaunchKernelGGL((conv_dgrad_pl_kernel<BM_, BN_, WM_, WN_, NB_, 3>), grid, dim3(64 * WM_ * WN_), 0, s, dy, dp, dx, add_src,     \
+                         add_mask_src, g, p.NT, p.wk, slab, stat);                                                                     \
     BDV_LAUNCH_CHECK("bdv_conv_dgrad_pl");                                                                                             \
     if (p.wk.split > 1) {                                                                                                              \
       hipLaunchKernelGGL((conv_dgrad_fixup_kernel<BM_, BN_, WM_, WN_>), dim3(p.wk.rem_tiles), dim3(64 * WM_ * WN_), 0, s,              \
@@ -3198,13 +3228,14 @@ extern "C" int bdv_conv_wgrad_pl_splits(const bdv_conv_geom* gg) {
 }
 
 extern "C" int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const bdv_conv_geom* gg, void* slab, size_t slab_bytes,
-                                         void* stream) {
+                                         int pieces, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_wgrad_partial_pl")) return e;
+  BDV_REQUIRE(pieces == 3 || pieces == 1, "bdv_conv_wgrad_partial_pl: pieces = %d (3 or 1)", pieces);
   BDV_REQUIRE(dy && x && slab, "bdv_conv_wgrad_partial_pl: null pointer");
   BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(slab), "bdv_conv_wgrad_partial_pl: pointers must be 16-byte aligned");
   if (!pl_wgrad_ok(gg)) {
     int splits = 0;
-    return wgrad_partial("bdv_conv_wgrad_partial_pl", dy, x, gg, slab, slab_bytes, (hipStream_t)stream, &splits, true);
+    return wgrad_partial("bdv_conv_wgrad_partial_pl", dy, x, gg, slab, slab_bytes, (hipStream_t)stream, &splits, pieces == 3);
   }
   const WgradPlPlan p = plan_wgrad_pl(gg);
   const size_t need = (size_t)p.splits * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(float);
@@ -3221,20 +3252,22 @@ extern "C" int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const 
     fprintf(stderr, "[bdv plan] wgrad_pl %dx%d Cin %d Cout %d k%d s%d: %dx%d tiles %d -> splits %d x %d k-iters\n", gg->H, gg->W, gg->Cin,
             gg->Cout, gg->R, gg->stride, p.BM, p.BN, p.MTw * p.NTw, p.splits, p.kt_per_split);
   const bool incr = g.Ho * g.Wo > BK && BK / g.Wo + 1 <= g.Ho;
+#define BDV_WGRAD_PL2(BM_, BN_, INCR_, NP_)                                                                                      \
+  hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, INCR_, NP_>), grid, dim3(512), 0, s, dy, x, (float*)slab, g, p.MTw, p.NTw,    \
+                     p.kt_per_split)
 #define BDV_WGRAD_PL(BM_, BN_)                                                                                                   \
   do {                                                                                                                           \
-    if (incr)                                                                                                                    \
-      hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, true>), grid, dim3(512), 0, s, dy, x, (float*)slab, g, p.MTw, p.NTw,      \
-                         p.kt_per_split);                                                                                        \
-    else                                                                                                                         \
-      hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, false>), grid, dim3(512), 0, s, dy, x, (float*)slab, g, p.MTw, p.NTw,     \
-                         p.kt_per_split);                                                                                        \
+    if (incr && pieces == 3) BDV_WGRAD_PL2(BM_, BN_, true, 3);                                                                   \
+    else if (pieces == 3) BDV_WGRAD_PL2(BM_, BN_, false, 3);                                                                     \
+    else if (incr) BDV_WGRAD_PL2(BM_, BN_, true, 1);                                                                             \
+    else BDV_WGRAD_PL2(BM_, BN_, false, 1);                                                                                      \
   } while (0)
   if (p.BM == 256 && p.BN == 256) BDV_WGRAD_PL(256, 256);
   else if (p.BM == 256) BDV_WGRAD_PL(256, 128);
   else if (p.BN == 256) BDV_WGRAD_PL(128, 256);
   else BDV_WGRAD_PL(128, 128);
 #undef BDV_WGRAD_PL
+#undef BDV_WGRAD_PL2
   BDV_LAUNCH_CHECK("bdv_conv_wgrad_partial_pl");
   return BDV_OK;
 }

@@ -109,13 +109,19 @@ def _x3_default(name):
 FPROP_X3 = _x3_default('BDVCIL_FPROP_X3')
 
 
+PIECES = 3      # 3: fp32-level products from three bf16 pieces per operand; 1: single bf16 product (reduced precision, 'bf16x1')
+
+
 def set_conv_arith(mode: str):
-    """'bf16x3' (default) or 'f32mfma' for fprop, dgrad and wgrad at once; returns the previous (fprop, dgrad, wgrad) flags."""
-    global FPROP_X3, DGRAD_X3, WGRAD_X3
-    if mode not in ('bf16x3', 'f32mfma'):
-        raise ValueError(f"set_conv_arith: unknown mode {mode!r} ('bf16x3' | 'f32mfma')")
+    """'bf16x3' (default), 'f32mfma', or the reduced-precision 'bf16x1' (BASELINE config 5: operands rounded to bf16, one MFMA
+    product, fp32 accumulate and tensors) for fprop, dgrad and wgrad at once; returns the previous (fprop, dgrad, wgrad) flags.
+    Leaving 'bf16x1' needs another ``set_conv_arith`` call (the flags alone do not restore ``PIECES``)."""
+    global FPROP_X3, DGRAD_X3, WGRAD_X3, PIECES
+    if mode not in ('bf16x3', 'f32mfma', 'bf16x1'):
+        raise ValueError(f"set_conv_arith: unknown mode {mode!r} ('bf16x3' | 'f32mfma' | 'bf16x1')")
     prev = (FPROP_X3, DGRAD_X3, WGRAD_X3)
-    FPROP_X3 = DGRAD_X3 = WGRAD_X3 = (mode == 'bf16x3')
+    FPROP_X3 = DGRAD_X3 = WGRAD_X3 = (mode != 'f32mfma')
+    PIECES = 1 if mode == 'bf16x1' else 3
     return prev
 
 
@@ -165,7 +171,7 @@ def conv_kernel_name(g: ConvGeom, kind: str, x3: Optional[bool] = None) -> str:
     k = {'fprop': 0, 'dgrad': 1, 'wgrad': 2}[kind]
     flag = (FPROP_X3, DGRAD_X3, WGRAD_X3)[k] if x3 is None else x3
     buf = ctypes.create_string_buffer(128)
-    check(lib().bdv_conv_kernel_name(ctypes.byref(g), k, int(bool(flag)), buf, 128), 'bdv_conv_kernel_name')
+    check(lib().bdv_conv_kernel_name(ctypes.byref(g), k, (2 if PIECES == 1 else 1) if flag else 0, buf, 128), 'bdv_conv_kernel_name')
     return buf.value.decode()
 
 
@@ -182,11 +188,11 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
     ws = _conv_ws(g, 0, x.device, ws_tag)
     part = aff = None
     use_x3 = FPROP_X3 if x3 is None else x3
-    use_pl = bool(use_x3 and USE_PL and lib().bdv_conv_uses_planes(ctypes.byref(g), 0))
+    use_pl = bool(use_x3 and USE_PL and lib().bdv_conv_uses_planes(ctypes.byref(g), 0, PIECES))
     if bn_stats:
         if affine is not None:
             raise ValueError('conv_fprop: bn_stats and affine exclude each other')
-        rows = (lib().bdv_conv_fprop_pl_stat_rows if use_pl else lib().bdv_conv_fprop_stat_rows)(ctypes.byref(g))
+        rows = lib().bdv_conv_fprop_pl_stat_rows(ctypes.byref(g), PIECES) if use_pl else lib().bdv_conv_fprop_stat_rows(ctypes.byref(g))
         if rows <= 0:
             check(-1, 'bdv_conv_fprop_stat_rows')
         part = torch.empty((2, rows, g.Cout), dtype=torch.float32, device=x.device)
@@ -200,7 +206,7 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
     if use_pl:
         planes_f, _ = weight_planes(w, g)
         check(lib().bdv_conv_fprop_pl(_p(x), _p(w), _p(planes_f), _p(y), ctypes.byref(g), _p(part),
-                                      ctypes.byref(aff) if aff is not None else None, _p(ws), ws.numel(), _stream()),
+                                      ctypes.byref(aff) if aff is not None else None, _p(ws), ws.numel(), PIECES, _stream()),
               'bdv_conv_fprop_pl')
         return (y, part) if bn_stats else y
     fn = lib().bdv_conv_fprop_x3 if use_x3 else lib().bdv_conv_fprop
@@ -230,7 +236,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
         _chk(add_mask_src, (g.N * g.H * g.W * g.Cin // 32,), dtype=torch.int32, name='add_mask_src')
     fuse = partial = None
     use_x3 = (DGRAD_X3 if x3 is None else x3) and g.Cin % 64 == 0
-    use_pl = bool(use_x3 and USE_PL and lib().bdv_conv_uses_planes(ctypes.byref(g), 1))
+    use_pl = bool(use_x3 and USE_PL and lib().bdv_conv_uses_planes(ctypes.byref(g), 1, PIECES))
     if bn_stats is not None:
         y, mask, mean, invstd = bn_stats
         _chk_conv(y, (g.N, g.H, g.W, g.Cin), g, 'y')
@@ -238,7 +244,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
         _chk(invstd, (g.Cin,), name='invstd')
         if mask is not None:
             _chk(mask, (y.numel() // 32,), dtype=torch.int32, name='relu_mask')
-        rows = (lib().bdv_conv_dgrad_pl_stat_rows if use_pl else lib().bdv_conv_dgrad_stat_rows)(ctypes.byref(g))
+        rows = lib().bdv_conv_dgrad_pl_stat_rows(ctypes.byref(g), PIECES) if use_pl else lib().bdv_conv_dgrad_stat_rows(ctypes.byref(g))
         if rows <= 0:
             check(-1, 'bdv_conv_dgrad_stat_rows')
         partial = torch.empty((2, rows, g.Cin), dtype=torch.float32, device=dy.device)
@@ -248,7 +254,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
     if use_pl:
         _, planes_d = weight_planes(w, g)
         check(lib().bdv_conv_dgrad_pl(_p(dy), _p(w), _p(planes_d), _p(dx), _p(add_src), _p(add_mask_src), ctypes.byref(g),
-                                      ctypes.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), _stream()),
+                                      ctypes.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), PIECES, _stream()),
               'bdv_conv_dgrad_pl')
         return dx if bn_stats is None else (dx, partial)
     if use_x3 and g.Cin % 128 == 0:
@@ -582,7 +588,10 @@ def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, x3: Optio
         check(-1, 'bdv_conv_wgrad_splits')
     slab = torch.empty((splits, g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
     fn = lib().bdv_conv_wgrad_partial_pl if use_pl else lib().bdv_conv_wgrad_partial_x3 if use_x3 else lib().bdv_conv_wgrad_partial
-    check(fn(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, _stream()), 'bdv_conv_wgrad_partial')
+    if use_pl:
+        check(fn(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, PIECES, _stream()), 'bdv_conv_wgrad_partial_pl')
+    else:
+        check(fn(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, _stream()), 'bdv_conv_wgrad_partial')
     if dw is None:
         dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
     return slab, dw

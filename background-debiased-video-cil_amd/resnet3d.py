@@ -1,7 +1,7 @@
 """I3D-ResNet50 (UPSTREAM mmaction2 ``ResNet3d`` / ``Bottleneck3d`` / ``I3DHead`` / ``Recognizer3D`` as configured by
 configs/_base_/models/i3d_r50.py:1-27) on the same HIP kernels as the TSM path -- SURVEY.md section 8(f) rank 4,
 BASELINE.json config 4.  Parity unpinned: mmaction2 is not vendored and the reference holds no fixture for this model; the CPU
-restatement is oracle/i3d_oracle.py.
+restatement used by the parity tests lives in the checker directory (i3d_*.py).
 
 How the 3-D network maps onto the 2-D kernels (activations stay fp32 NHWC frames, ``[B*T][H][W][C]``):
 

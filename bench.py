@@ -29,6 +29,9 @@ import torch.distributed as dist  # noqa: E402
 R50_FLOP_PER_CLIP = 194.29e9       # BASELINE.md section 2 (fwd+bwd, conv MACs only, stem dgrad excluded)
 R50_KD_FLOP_PER_CLIP = 259.7e9     # + the frozen previous model's forward
 R50_FWD_FLOP_PER_CLIP = 65.39e9    # forward only (2 x 8 x 4.0871 GMAC)
+# BASELINE config 4: I3D-ResNet50 on 32 x 224 x 224 clips: 33.127 GMAC of convolutions per clip (oracle/i3d_oracle.py), of
+# which 9.441 GMAC in the 5x7x7 stem (no input gradient): fwd + bwd = 6 x 33.127 - 2 x 9.441 GFLOP
+I3D_FLOP_PER_CLIP = 6 * 33.127399424e9 - 2 * 9.44111616e9
 PEAK_F32_MFMA = 157.3e12           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 PEAK_BF16_MFMA = 2516.6e12         # v_mfma_f32_32x32x16_bf16: 32 cycles per 32x32x16 on 1024 SIMDs at 2.4 GHz, dense
 # An fp32 product formed from three bf16 pieces per operand costs six bf16 MFMA products: the MFMA-bound rate of the
@@ -234,15 +237,18 @@ def main():
     ap.add_argument('--head', default='SimpleLinear', choices=['SimpleLinear', 'LocalSimilarityClassifier'])
     ap.add_argument('--loss', default='CrossEntropyLoss', choices=['CrossEntropyLoss', 'LSCLoss'])
     ap.add_argument('--dropout', type=float, default=0.5)
-    ap.add_argument('--workload', default='ce', choices=['ce', 'cil', 'predict'],
+    ap.add_argument('--workload', default='ce', choices=['ce', 'cil', 'predict', 'i3d'],
                     help="'ce': BASELINE config 2 (the metric); 'cil': config 3 step = uint8 background-mix front-end, LSC head + "
                          "LSCLoss, feature-KD against a frozen previous model (task >= 1), clip 1.0, SGD; 'predict': eval forward "
-                         "+ representations of BaseCIL.predict_step (SURVEY section 8(f) rank 1), no backward")
+                         "+ representations of BaseCIL.predict_step (SURVEY section 8(f) rank 1), no backward; 'i3d': BASELINE config 4, "
+                         "I3D-ResNet50 fwd+bwd+SGD on 32x3x224x224 clips (default batch 16)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--arith', default='bf16x3', choices=['bf16x3', 'f32mfma'],
+    ap.add_argument('--arith', default='bf16x3', choices=['bf16x3', 'f32mfma', 'bf16x1'],
                     help="conv arithmetic: 'bf16x3' (default; fp32 products from three bf16 pieces per operand, six bf16 MFMA "
-                         "products, fp32 accumulate) or 'f32mfma' (v_mfma_f32_32x32x2_f32 kernels)")
+                         "products, fp32 accumulate), 'f32mfma' (v_mfma_f32_32x32x2_f32 kernels), or the REDUCED-PRECISION 'bf16x1' of BASELINE "
+                         "config 5 (operands rounded to bf16, one MFMA product, fp32 accumulate and tensors; use with --batch 64; "
+                         "reported with dtype bf16, never as the headline metric)")
     ap.add_argument('--selftest-cpu', action='store_true', help=argparse.SUPPRESS)   # launcher test: gloo ranks, no GPU
     args = ap.parse_args()
 
@@ -279,10 +285,23 @@ def main():
 
     cil = args.workload == 'cil'
     predict = args.workload == 'predict'
+    i3d = args.workload == 'i3d'
+    if i3d and args.batch == 32:
+        args.batch = 16                       # BASELINE config 4: batch 16 per GPU
     if cil or predict:
         args.head, args.loss = 'LocalSimilarityClassifier', 'LSCLoss'
     torch.manual_seed(0)
-    model = bd.build_model(model_cfg(args.depth, args.classes, args.head, args.loss, args.dropout)).to(dev)
+    if i3d:
+        cfg = dict(type='Recognizer3D',
+                   backbone=dict(type='ResNet3d', pretrained2d=True, pretrained=None, depth=50, conv1_kernel=(5, 7, 7), conv1_stride_t=2,
+                                 pool1_stride_t=2, conv_cfg=dict(type='Conv3d'), norm_eval=False,
+                                 inflate=((1, 1, 1), (1, 0, 1, 0), (1, 0, 1, 0, 1, 0), (0, 1, 0)), zero_init_residual=False),
+                   cls_head=dict(type='I3DHead', num_classes=args.classes, in_channels=2048, spatial_type='avg',
+                                 dropout_ratio=args.dropout, init_std=0.01),
+                   train_cfg=None, test_cfg=dict(average_clips='prob'))         # configs/_base_/models/i3d_r50.py:1-27
+    else:
+        cfg = model_cfg(args.depth, args.classes, args.head, args.loss, args.dropout)
+    model = bd.build_model(cfg).to(dev)
     model.train()
     reducer = None
     if use_dist:
@@ -325,6 +344,14 @@ def main():
             return bd.base_training_step(m, data, current_task=1, prev_model=prev, current_hooks=cur_hooks,
                                          prev_hooks=prev_hooks, kd_modules_names=names, kd_weight_by_module=[0.01] * 5,
                                          adaptive_scale_factors=[1.0, 3.3466401061363023])
+    elif i3d:
+        imgs = torch.randn(args.batch, 1, 3, 32, 224, 224, generator=g).to(dev)
+
+        def loss_fn(m, b):
+            out = m(b['imgs'], b['label'])
+            out['loss'] = out['loss_cls']
+            return out
+        batch = dict(imgs=imgs, label=labels)
     else:
         imgs = torch.randn(args.batch, 8, 3, 224, 224, generator=g).to(dev)
         batch = dict(imgs=imgs, label=labels)
@@ -359,19 +386,25 @@ def main():
     if rank == 0:
         clips = args.batch * world * args.steps
         value = clips / dt
-        flop_per_clip = (R50_KD_FLOP_PER_CLIP if cil else R50_FWD_FLOP_PER_CLIP if predict else R50_FLOP_PER_CLIP) if args.depth == 50 else None
+        flop_per_clip = (I3D_FLOP_PER_CLIP if i3d else R50_KD_FLOP_PER_CLIP if cil else R50_FWD_FLOP_PER_CLIP if predict else R50_FLOP_PER_CLIP) if args.depth == 50 else None
         res = {
-            'metric': ('clips/sec fwd+bwd TSM-R50 8x224^2 bs32/GPU' if args.depth == 50 else f'clips/sec fwd+bwd TSM-R{args.depth}')
+            'metric': (f'clips/sec fwd+bwd TSM-R50 8x224^2 bs{args.batch}/GPU, bf16 MFMA tiles (BASELINE config 5; not the headline metric)'
+                       if args.arith == 'bf16x1' and args.depth == 50 and not (cil or predict or i3d) else
+                       'clips/sec fwd+bwd I3D-R50 32x224^2 bs16/GPU (BASELINE config 4; not the headline metric)' if i3d else
+                       'clips/sec fwd+bwd TSM-R50 8x224^2 bs32/GPU' if args.depth == 50 else f'clips/sec fwd+bwd TSM-R{args.depth}')
                       + (' (CIL step: bg-mix front-end + KD teacher + LSCLoss)' if cil else '')
                       + (' (predict_step: eval forward + representations, no backward)' if predict else ''),
             'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000.0 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'bf16' if args.arith == 'bf16x1' else 'f32', 'data': 'synthetic',
             'config': {'workload': ('CIL task-1 step (uint8 bg-mix front-end, frozen teacher forward, 5 feature-KD MSE terms, clip 1.0): ' if cil else '')
-                                   + f'TSM-ResNet{args.depth} ' + ('eval forward + clip representations (predict_step)' if predict else 'fwd+bwd+SGD step') + f', synthetic {args.batch}x8x3x224x224 clips per GPU, '
-                                   f'{args.classes} classes, {args.head}+{args.loss}, dropout {args.dropout}, random-init weights; '
+                                   + (f'I3D-ResNet50 (ResNet3d, 3x1x1 inflation) fwd+bwd+SGD step, synthetic {args.batch}x3x32x224x224 clips per GPU, ' if i3d else
+                                      f'TSM-ResNet{args.depth} ' + ('eval forward + clip representations (predict_step)' if predict else 'fwd+bwd+SGD step') + f', synthetic {args.batch}x8x3x224x224 clips per GPU, ')
+                                   + f'{args.classes} classes, {"I3DHead" if i3d else args.head}+{args.loss}, dropout {args.dropout}, random-init weights; '
                                    + ('fp32 tensors, accumulators and results; conv products: fp32 via 3xbf16 split, 6 MFMA products, fp32 accumulate '
                                       '(dropped terms <= 2^-24 relative)' if args.arith == 'bf16x3' else
+                                      'REDUCED PRECISION (BASELINE config 5): conv operands rounded to bf16, one bf16 MFMA product, fp32 accumulate, '
+                                      'fp32 tensors' if args.arith == 'bf16x1' else
                                       'fp32 tensors and results; conv products on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)'),
                        'conv_arith': args.arith,
                        'clips_per_gpu': args.batch, 'global_batch': args.batch * world, 'parallelism': f'dp{world}',
@@ -388,7 +421,7 @@ def main():
             dom = max(conv, key=lambda k: conv[k]['ms'])
             d = conv[dom]
             bf16_pieces = '_x3_' in dom or '_pl_' in dom
-            peak = PEAK_BF16X3 if bf16_pieces else PEAK_F32_MFMA
+            peak = PEAK_BF16_MFMA if args.arith == 'bf16x1' and bf16_pieces else PEAK_BF16X3 if bf16_pieces else PEAK_F32_MFMA
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
             tot_ms = sum(v['ms'] for v in by.values())
             tot_fl = sum(v['flops'] for v in by.values())
@@ -411,7 +444,7 @@ def main():
                 'conv_ms_per_step': round(tot_ms / timed_steps, 3), 'conv_tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                 'kernel_timed_steps': timed_steps, 'kernel_timing_note': 'HIP events around every conv call on every 8th timed step; on those steps the weight gradients run on the main stream (elsewhere on a side stream, overlapped with the BatchNorm backward passes)',
             }
-        if world == 1 and not args.no_cpu_baseline and not cil and not predict:
+        if world == 1 and not args.no_cpu_baseline and not cil and not predict and not i3d:
             res['cpu_baseline'] = cpu_baseline(args.depth, args.classes, args.head, args.loss)
         print(json.dumps(res), flush=True)
     if use_dist:

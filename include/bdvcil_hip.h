@@ -121,8 +121,13 @@ int bdv_conv_dgrad_x3(const float* dy, const float* w, const float* w_t, float* 
  * (either may be NULL; Cin and Cout multiples of 32).  bdv_conv_fprop_pl / bdv_conv_dgrad_pl take the planes beside w and
  * behave like bdv_conv_fprop / bdv_conv_dgrad (same epilogues, workspace = bdv_conv_workspace_bytes); shapes their
  * 8-wave kernels do not cover (Cout resp. Cin not a multiple of 128, the stem) run the other kernels on w.  The fused
- * statistics partials have bdv_conv_fprop_pl_stat_rows(g) / bdv_conv_dgrad_pl_stat_rows(g) rows (one per row tile of the
- * kernel that will run, 128 or 256 rows). */
+ * statistics partials have bdv_conv_fprop_pl_stat_rows(g, pieces) / bdv_conv_dgrad_pl_stat_rows(g, pieces) rows (one per row
+ * tile of the kernel that will run, 128 or 256 rows).
+ * pieces = 3 is the arithmetic described above.  pieces = 1 is the REDUCED-PRECISION arithmetic of BASELINE config 5 ("MFMA
+ * fp16 tiles"; the reference's trainer is precision 32, libs/cil/cil.py:744-756, so there are no reference numerics for it):
+ * each operand value is rounded to bf16 (only the hi plane is used), one v_mfma_f32_32x32x16_bf16 product per step, fp32
+ * accumulate, fp32 tensors in HBM -- what torch.autocast(bfloat16) computes for a convolution, without the bf16 output rounding.
+ * Error of a result: ~2^-9 relative per product, i.e. ~1e-3 .. 1e-2 of the output scale (tests/test_bf16x1_gpu.py). */
 size_t bdv_conv_weight_planes_bytes(const bdv_conv_geom* g);
 int bdv_conv_split_weights(const float* w, const bdv_conv_geom* g, void* planes_fprop, void* planes_dgrad, void* stream);
 /* Test / A-B hook, process-wide and not thread-safe: force the tile configuration of the two entry points below
@@ -130,17 +135,19 @@ int bdv_conv_split_weights(const float* w, const bdv_conv_geom* g, void* planes_
 int bdv_conv_debug_force_tile(int cfg);
 /* 1 when bdv_conv_fprop_pl (kind 0) / bdv_conv_dgrad_pl (kind 1) will read the weight planes for this geometry, 0 when it
  * runs a kernel that takes w (the caller then need not build the planes). */
-int bdv_conv_uses_planes(const bdv_conv_geom* g, int kind);
+int bdv_conv_uses_planes(const bdv_conv_geom* g, int kind, int pieces);
 /* Name of the main kernel that a call with this geometry launches, as a profiler prints it (kind 0 fprop, 1 dgrad, 2 wgrad;
- * arith 0 = the fp32-MFMA entry points, 1 = the *_pl entry points).  For profiles and per-kernel accounting. */
+ * arith 0 = the fp32-MFMA entry points, 1 = the *_pl entry points, 2 = the same with pieces = 1).  For profiles and per-kernel
+ * accounting. */
 int bdv_conv_kernel_name(const bdv_conv_geom* g, int kind, int arith, char* out, size_t n);
-int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* g);
-int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* g);
+int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* g, int pieces);
+int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* g, int pieces);
 int bdv_conv_fprop_pl(const float* x, const float* w, const void* planes_fprop, float* y, const bdv_conv_geom* g,
-                      float* bn_partial, const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, void* stream);
+                      float* bn_partial, const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, int pieces,
+                      void* stream);
 int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* planes_dgrad, float* dx, const float* add_src,
                       const uint32_t* add_mask_src, const bdv_conv_geom* g, const bdv_bn_stat_fuse* bn_stat, void* workspace,
-                      size_t workspace_bytes, void* stream);
+                      size_t workspace_bytes, int pieces, void* stream);
 
 /* wgrad: dw[Cout,R,S,Cin] = beta * dw + sum_pixels dy (x) shift(x).  Deterministic split-K:
  * partial slabs go to `workspace`, a second kernel reduces them in fixed order. */
@@ -163,7 +170,7 @@ int bdv_wgrad_reduce_batched(const float* const* slabs, float* const* dws, const
  * bdv_conv_wgrad_pl_splits(g) partial products of dw's size; reduce with bdv_wgrad_reduce_batched. */
 int bdv_conv_wgrad_pl_splits(const bdv_conv_geom* g);
 int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const bdv_conv_geom* g, void* slab, size_t slab_bytes,
-                              void* stream);
+                              int pieces, void* stream);
 /* EXPERIMENTAL counterpart of bdv_conv_fprop_x3 for the weight gradient's main kernel (128x128 tiles, i.e. Cout and Cin
  * multiples of 128; other shapes run the fp32-MFMA kernels).  Same slab layout and split count as bdv_conv_wgrad_partial. */
 int bdv_conv_wgrad_partial_x3(const float* dy, const float* x, const bdv_conv_geom* g, void* slab, size_t slab_bytes,

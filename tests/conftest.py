@@ -27,4 +27,5 @@ def conv_arith(request):
     from bdvcil_amd import kernels as K
     prev = K.set_conv_arith(request.param)
     yield request.param
+    K.set_conv_arith('bf16x3')
     K.FPROP_X3, K.DGRAD_X3, K.WGRAD_X3 = prev

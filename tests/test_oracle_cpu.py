@@ -197,3 +197,29 @@ def test_acm_smooth_ce_matches_reference_golden():
         loss.backward()
         assert torch.allclose(loss, _t(gz[p + 'loss']), rtol=1e-6, atol=1e-7)
         assert torch.allclose(score.grad, _t(gz[p + 'dscore']), rtol=1e-5, atol=1e-8)
+
+
+def test_i3d_oracle_and_plugin_surface():
+    """oracle/i3d_oracle.py (parity unpinned) against the facts available here: 33.13 GMAC of convolutions per 32 x 224 x 224
+    clip ("about 33 GMAC/clip by my count"), the inflation pattern of configs/_base_/models/i3d_r50.py:15
+    (3 + 2 + 3 + 1 inflated blocks), and a state_dict that the product's Recognizer3D -- built from that config through the
+    registry -- loads key for key."""
+    import torch.nn as nn
+    from oracle import i3d_oracle as I
+    import bdvcil_amd as bd
+    assert I.i3d_conv_macs(32, 224) == 33127399424
+    ref = I.Recognizer3D(400)
+    inflated = [isinstance(m, nn.Conv3d) and m.kernel_size == (3, 1, 1) for m in ref.modules()]
+    assert sum(inflated) == 9
+    cfg = dict(type='Recognizer3D',
+               backbone=dict(type='ResNet3d', pretrained2d=True, pretrained=None, depth=50, conv1_kernel=(5, 7, 7), conv1_stride_t=2,
+                             pool1_stride_t=2, conv_cfg=dict(type='Conv3d'), norm_eval=False,
+                             inflate=((1, 1, 1), (1, 0, 1, 0), (1, 0, 1, 0, 1, 0), (0, 1, 0)), zero_init_residual=False),
+               cls_head=dict(type='I3DHead', num_classes=400, in_channels=2048, spatial_type='avg', dropout_ratio=0.5, init_std=0.01),
+               train_cfg=None, test_cfg=dict(average_clips='prob'))
+    mod = bd.build_model(cfg)
+    assert set(mod.state_dict()) == set(ref.state_dict())
+    mod.load_state_dict(ref.state_dict())
+    assert sum(p.numel() for p in mod.parameters()) == sum(p.numel() for p in ref.parameters()) == 27223872 + 2048 * 400 + 400
+    with pytest.raises(FileNotFoundError):
+        bd.build_model(dict(cfg, backbone=dict(cfg['backbone'], pretrained='torchvision://resnet50')))
