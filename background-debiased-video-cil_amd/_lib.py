@@ -45,6 +45,7 @@ class BnStatFuse(Structure):
 SIGNATURES = {
     'bdv_last_error': (c_char_p, []),
     'bdv_abi_version': (c_int, []),
+    'bdv_source_hash': (c_char_p, []),
     'bdv_conv_workspace_bytes': (c_size_t, [POINTER(ConvGeom), c_int]),
     'bdv_conv_fprop_stat_rows': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_fprop': (c_int, [P, P, P, POINTER(ConvGeom), P, POINTER(ConvAffine), P, c_size_t, P]),
@@ -121,6 +122,24 @@ class HipExtensionError(RuntimeError):
     pass
 
 
+HASHED_SOURCES = ('conv_mfma.hip', 'bn.hip', 'pool_frontend.hip', 'head_loss.hip', 'repr.hip', 'augment.hip', 'optim.hip',
+                  'api_common.cpp', 'common.h', 'Makefile', '../../include/bdvcil_hip.h')   # = HASHED in csrc/Makefile
+
+
+def source_hash():
+    """sha256 of the in-tree sources in the Makefile's order (None when a binary-only install carries no sources)."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.dirname(LIB_PATH)
+    for name in HASHED_SOURCES:
+        path = os.path.join(base, name)
+        if not os.path.exists(path):
+            return None
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def lib():
     """Return the loaded library, loading it on first use.  Raises if it is not built."""
     global _lib
@@ -136,6 +155,10 @@ def lib():
             fn.argtypes = args
         if handle.bdv_abi_version() != ABI_VERSION:
             raise HipExtensionError(f'ABI mismatch: library {handle.bdv_abi_version()} != binding {ABI_VERSION}')
+        want, have = source_hash(), handle.bdv_source_hash().decode()
+        if want is not None and want != have:
+            raise HipExtensionError(f'stale library: {LIB_PATH} was built from other sources (hash {have[:12]}, in-tree '
+                                    f'{want[:12]}). Rebuild: make -C {os.path.dirname(LIB_PATH)}')
         _lib = handle
     return _lib
 

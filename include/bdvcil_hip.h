@@ -51,6 +51,9 @@ typedef struct bdv_conv_geom {
 
 const char* bdv_last_error(void);
 int bdv_abi_version(void);
+/* sha256 (hex) of the sources this library was built from, in the Makefile's HASHED order; the binding compares it with
+ * the sources it finds in-tree and refuses a stale build. */
+const char* bdv_source_hash(void);
 
 /* ---- convolution = implicit GEMM on v_mfma_f32_32x32x2_f32 --------------------------------
  * fprop replaces F.conv2d inside ConvModule (+ UPSTREAM TemporalShift.shift when fold > 0:

@@ -32,6 +32,19 @@ def test_c_abi_exports_every_declared_symbol():
     assert bd._lib.lib().bdv_abi_version() == bd._lib.ABI_VERSION
 
 
+def test_stale_library_is_refused(monkeypatch):
+    """The binding loads only a library built from the sources next to it (bdv_source_hash == sha256 of csrc + header)."""
+    L = bd._lib
+    assert L.lib().bdv_source_hash().decode() == L.source_hash()
+    mk = open(os.path.join(os.path.dirname(L.LIB_PATH), 'Makefile')).read()
+    hashed = re.search(r'^SRCS = (.*)$', mk, re.M).group(1).split() + re.search(r'^HASHED = \$\(SRCS\) (.*)$', mk, re.M).group(1).split()
+    assert tuple(hashed) == L.HASHED_SOURCES
+    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, 'source_hash', lambda: '0' * 64)
+    with pytest.raises(L.HipExtensionError, match='stale library'):
+        L.lib()
+
+
 def test_registry_contract():
     assert 'CILRecognizer2D' in bd.RECOGNIZERS and 'ResNetTSM' in bd.BACKBONES and 'IncrementalTSMHead' in bd.HEADS
     assert 'LSCLoss' in bd.LOSSES and 'ACMSmoothCE' in bd.LOSSES

@@ -132,7 +132,11 @@ def test_i3d_train_step(dev, conv_arith):
     r64['loss_cls'].backward()
     ol = mod(imgs.to(dev), labels.to(dev))
     ol['loss_cls'].backward()
-    assert abs(ol['loss_cls'].item() - rl['loss_cls'].item()) <= 1e-4 * max(1.0, abs(rl['loss_cls'].item()))
+    # layer4's BatchNorms normalise over 8 samples here (2 clips x 1 frame x 2x2): the fp32 CPU oracle itself is 3.5e-4 away
+    # from its fp64 run in the loss and 1.1e-4 (relative) in a running variance.  Every bar below is therefore stated against
+    # the fp64 oracle: 3x the fp32 CPU oracle's own distance from it, plus the plain tolerance.
+    l64 = r64['loss_cls'].item()
+    assert abs(ol['loss_cls'].item() - l64) <= 3 * abs(rl['loss_cls'].item() - l64) + 1e-4 * max(1.0, abs(l64))
     assert abs(ol['top1_acc'].item() - rl['top1_acc'].item()) < 1e-6
     rp, r64p, op = dict(ref.named_parameters()), dict(ref64.named_parameters()), dict(mod.named_parameters())
     for name, p in rp.items():
@@ -140,12 +144,15 @@ def test_i3d_train_step(dev, conv_arith):
         assert tuple(op[name].grad.shape) == tuple(p.shape), name
         e_hip, e_f32 = _rel_l2(op[name].grad, r64p[name].grad), _rel_l2(p.grad, r64p[name].grad)
         assert e_hip <= 3 * e_f32 + 3e-2, (name, e_hip, e_f32)
-    rb, ob = dict(ref.named_buffers()), dict(mod.named_buffers())
+    rb, r64b, ob = dict(ref.named_buffers()), dict(ref64.named_buffers()), dict(mod.named_buffers())
     for name, b in rb.items():
         if name.endswith('num_batches_tracked'):
             assert int(ob[name].item()) == int(b.item()), name
         else:
-            assert (ob[name].cpu() - b).abs().max().item() <= 1e-4 * (b.abs().max().item() + 1e-12) + 1e-6, name
+            b64 = r64b[name]
+            e_hip = (ob[name].cpu().double() - b64).abs().max().item()
+            e_f32 = (b.double() - b64).abs().max().item()
+            assert e_hip <= 3 * e_f32 + 1e-4 * b64.abs().max().item() + 1e-6, (name, e_hip, e_f32)
     # one fused SGD step with the reference's parameter groups runs on the 5-D weights
     opt = bd.build_optimizer(mod, dict(type='SGD', constructor='CILTSMOptimizerConstructorImprovised',
                                        paramwise_cfg=dict(fc_lr_scale_factor=5.0), lr=0.01, momentum=0.9, weight_decay=1e-4))

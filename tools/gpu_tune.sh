@@ -8,6 +8,5 @@ step() {  # name, limit, command...
   tail -n 4 gpurun_out/$name.log
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$name] killed at its limit: stopping"; exit $rc; fi
 }
-step pytest_conv 900 python -m pytest tests/test_conv_gpu.py -m gpu -q -x
-step tune_conv 500 python tools/tune_conv.py
-step bench 400 python bench.py --steps 12 --warmup 4 --no-cpu-baseline
+step pytest_new 600 python -m pytest tests/test_i3d_gpu.py tests/test_bf16x1_gpu.py -m gpu -q
+FUSED=1 step tune_conv_fused 600 python tools/tune_conv.py

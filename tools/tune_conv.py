@@ -1,7 +1,10 @@
 """Per-site timing of every kernel choice for fprop / dgrad at the TSM-R50 sites (N = 256 frames), in ONE process (timings
 taken on different boxes differ by several per cent): the round-1 bf16-piece kernels (operands split in the K loop, two
 workgroups per CU) and the 8-wave kernels on pre-split weight planes with each tile configuration forced in turn.
-Prints one row per site and direction with the time of every choice and the best one.  Dev tool, GPU only."""
+Prints one row per site and direction with the time of every choice and the best one.  FUSED=1 times the calls as the
+training step makes them: fprop with the BatchNorm statistics in its epilogue; dgrad of a block's conv1 (the shifted sites) with
+the identity-branch gradient + ReLU mask added and the BatchNorm-backward statistics taken, the other stride-1 dgrads with the
+statistics.  Dev tool, GPU only."""
 import os
 import sys
 
@@ -13,6 +16,7 @@ from bdvcil_amd._lib import check, lib
 from tools.bench_conv import SHAPES, timeit  # noqa: E402
 
 N = int(os.environ.get('N', 256))
+FUSED = os.environ.get('FUSED', '0') == '1'
 dev = torch.device('cuda:0')
 CFG = {0: '128x256', 1: '256x128', 2: '256x256', 3: '256x64'}
 
@@ -31,7 +35,19 @@ for (Cin, Cout, k, st, H, cnt, sh) in SHAPES:
     x = torch.randn(N, H, H, Cin, device=dev)
     w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
     dy = torch.randn(N, g.Ho, g.Wo, Cout, device=dev)
-    for name, ncols, fn in (('fprop', Cout, lambda: K.conv_fprop(x, w, g)), ('dgrad', Cin, lambda: K.conv_dgrad(dy, w, g))):
+    fp, dg = (lambda: K.conv_fprop(x, w, g)), (lambda: K.conv_dgrad(dy, w, g))
+    if FUSED:
+        fp = lambda: K.conv_fprop(x, w, g, bn_stats=True)  # noqa: E731
+        if st == 1:
+            yprev = torch.randn(N, H, H, Cin, device=dev)
+            mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (yprev.numel() // 32,), dtype=torch.int32, device=dev)
+            stats = (yprev, mask, torch.randn(Cin, device=dev), torch.rand(Cin, device=dev) + 0.5)
+            if sh:
+                src = torch.randn(N, H, H, Cin, device=dev)
+                dg = lambda: K.conv_dgrad(dy, w, g, add_src=src, add_mask_src=mask, bn_stats=stats)  # noqa: E731
+            else:
+                dg = lambda: K.conv_dgrad(dy, w, g, bn_stats=stats)  # noqa: E731
+    for name, ncols, fn in (('fprop', Cout, fp), ('dgrad', Cin, dg)):
         K.USE_PL = False
         t_old = timeit(fn)
         K.USE_PL = True
