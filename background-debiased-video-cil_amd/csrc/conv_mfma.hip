@@ -948,6 +948,71 @@ __global__ __launch_bounds__(256, 3) void conv_fprop_c4_kernel(const float* __re
   fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
 }
 
+// The stem in the bf16-piece arithmetic: loader of conv_fprop_c4_kernel, K loop of conv_fprop_x3_kernel (both operands are
+// split in the loader; a thread's 16-byte load is one filter tap = 4 consecutive K-values, which is store_split3's mapping).
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_fprop_c4_x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   float* __restrict__ y, Geom g, int NT, FpropEpi epi) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AP = BM / 32, BP = BN / 32;
+  static_assert(3 * (BM + BN) * X3_LDK * 2 >= WM * 32 * BN * 4, "the epilogue stages a tile pass in the same LDS");
+  __shared__ __attribute__((aligned(16))) unsigned short smem16[3 * (BM + BN) * X3_LDK];
+  unsigned short* const As = smem16;
+  unsigned short* const Bs = smem16 + 3 * BM * X3_LDK;
+  float* const smem = reinterpret_cast<float*>(smem16);
+  const int tile = xcd_remap(blockIdx.x, epi.MT * NT);
+  const int mt = tile / NT, nt = tile - mt * NT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;
+  const int arow = tid >> 3, kg = tid & 7;
+  const int HoWo = g.Ho * g.Wo;
+  const int RS = g.R * g.S;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * g.H * g.W * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, g.Cout * g.Ktot * 4, 0x00020000);
+
+  int a_base[AP], a_hi0[AP], a_wi0[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int m = mt * BM + arow + 32 * p;
+    const bool ok = m < g.M;
+    const int mm = ok ? m : 0;  // up to 2^23 output pixels here: exact integer division
+    const int n = mm / HoWo;
+    const int rem = mm - n * HoWo;
+    const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+    a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);
+    a_wi0[p] = wo * g.stride - g.pad_w;
+    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad_w) * 16;
+  }
+  float4 ra[AP], rb[BP];
+  auto load = [&](int kt) {
+    const int tap = kt * (BK / 4) + kg;  // this thread's filter tap
+    const int r = tap / g.S, s = tap - r * g.S;
+    const bool kv = tap < RS;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const bool v = kv && (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W;
+      ra[p] = buf_load16(xr, (a_base[p] + (r * g.W + s) * 16) | (v ? 0 : kOOB), 0);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p)
+      rb[p] = buf_load16(wr, (((nt * BN + arow + 32 * p) * g.Ktot + tap * 4) * 4) | (kv ? 0 : kOOB), 0);
+  };
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  const int nk = (g.Ktot + BK - 1) / BK;
+  load(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    store_split3<BM, AP>(As, ra, tid);
+    store_split3<BN, BP>(Bs, rb, tid);
+    __syncthreads();
+    if (kt + 1 < nk) load(kt + 1);
+    mma_stage_x3<TM, TN, 32 * WM, 32 * WN, BM, BN>(As, Bs, acc, wm0, wn0, lane);
+  }
+  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
+}
+
 // fix-up for the K-split remainder tiles: sum the `split` partial accumulators in slice order, then the same
 // element store (and BN column statistics) as the main kernel.  grid = rem_tiles, 256 threads mapped like the
 // main kernel.
@@ -2208,12 +2273,15 @@ __device__ __forceinline__ bf16x8_t pl_frag_tr(const unsigned char* __restrict__
   return __builtin_bit_cast(bf16x8_t, f);
 }
 
-template <int BM, int BN, bool INCR, int NP = 3>
-__global__ __launch_bounds__(512, 2) void conv_wgrad_pl_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                float* __restrict__ slab, Geom g, int MTw, int NTw,
-                                                                int kt_per_split) {
-  constexpr int WM = 2, WN = 4, NTHR = 512;
+// MTAP: the BN columns of a tile span BN / Cin whole filter taps (64-channel layers: a 3x3 filter row = 192 columns).
+// WM x WN waves; the 4-wave forms (64-wide tiles, 60-72 KB of LDS) run two workgroups per CU.
+template <int BM, int BN, int WM, int WN, bool INCR, int NP = 3, bool MTAP = false>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                         float* __restrict__ slab, Geom g, int MTw, int NTw,
+                                                                         int kt_per_split) {
+  constexpr int NTHR = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(TM >= 1 && TN >= 1 && (32 * (BM / 4)) % NTHR == 0 && (32 * (BN / 4)) % NTHR == 0, "tile / thread mapping");
   constexpr int AV = BM / 4, BV = BN / 4;
   constexpr int AP = 32 * AV / NTHR, BP = 32 * BV / NTHR;
   constexpr int PITCH_A = 2 * BM + 64, PITCH_B = 2 * BN + 64;
@@ -2244,19 +2312,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pl_kernel(const float* __re
     a_krow[p] = idx / AV;
     a_off[p] = (a_krow[p] * g.Cout + mt * BM + 4 * (idx % AV)) * 4;
   }
-  // B: column tile -> (tap, ci block); rows = input pixels of the tap
-  const int per_tap = g.Cin / BN;
-  const int tap = nt / per_tap;
-  const int ci0 = (nt - tap * per_tap) * BN;
-  const int b_r = tap / g.S - g.pad, b_s = tap % g.S - g.pad_w;
-  int b_krow[BP], b_off[BP], b_cls[BP];
+  // B: GEMM column nt * BN + j = (tap, ci) with ci fastest; rows = input pixels of the tap
+  int b_krow[BP], b_off[BP], b_cls[BP], b_r[BP], b_s[BP];
 #pragma unroll
   for (int p = 0; p < BP; ++p) {
     const int idx = tid + NTHR * p;
     b_krow[p] = idx / BV;
-    const int ci = ci0 + 4 * (idx % BV);
+    const int col = nt * BN + 4 * (idx % BV);
+    const int tap = MTAP ? col / g.Cin : (nt * BN) / g.Cin;   // one tap per tile unless MTAP
+    const int ci = col - tap * g.Cin;
+    b_r[p] = (!MTAP || tap < g.R * g.S) ? tap / g.S - g.pad : -(1 << 20);   // columns past the last tap (stem: 49 taps in 64) load zeros
+    b_s[p] = tap % g.S - g.pad_w;
     b_cls[p] = shift_class(ci, g.fold);
-    b_off[p] = ((b_r * g.W + b_s) * g.Cin + ci) * 4 + b_cls[p] * frame_bytes;
+    b_off[p] = ((b_r[p] * g.W + b_s[p]) * g.Cin + ci) * 4 + b_cls[p] * frame_bytes;
   }
 
   const int kt_begin = split * kt_per_split;
@@ -2321,7 +2389,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pl_kernel(const float* __re
         t = n % g.T;
         off = ((n * g.H + hi) * g.W + wi_) * px + b_off[p];
       }
-      const bool v = mok && (unsigned)(hi + b_r) < (unsigned)g.H && (unsigned)(wi_ + b_s) < (unsigned)g.W &&
+      const bool v = mok && (unsigned)(hi + b_r[p]) < (unsigned)g.H && (unsigned)(wi_ + b_s[p]) < (unsigned)g.W &&
                      (unsigned)(t + b_cls[p]) < (unsigned)g.T;
       rb[p] = buf_load16(xr, off | (v ? 0 : kOOB), 0);
     }
@@ -2370,7 +2438,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pl_kernel(const float* __re
   float* out = slab + (size_t)split * g.Cout * g.Ktot;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int col = tap * g.Cin + ci0 + 32 * WN * j + 32 * wn + (lane & 31);
+    const int col = nt * BN + 32 * WN * j + 32 * wn + (lane & 31);
+    if (MTAP && col >= g.Ktot) continue;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -2580,10 +2649,14 @@ int pl_tile_override() {
 //   * multiples of 256 columns: fprop 256x256 tiles when there are exactly 256 columns and K >= 512, else 128x256 tiles for
 //     K >= 512 or K = 64, else the x3 kernels (K = 128 / 256: eight or fewer K-steps cannot hide an 8-wave workgroup's
 //     prologue and epilogue, two smaller workgroups per CU can); dgrad 256x256 tiles except for short K with >= 1024 columns
-//     and for stride-2 3x3 filters (four parity classes with a quarter of the taps each).
+//     and for stride-2 3x3 filters (four parity classes with a quarter of the taps each);
+//   * dgrad of a block's conv1 (1x1 with the temporal shift): in the training step its epilogue adds the identity-branch gradient
+//     and takes the BatchNorm-backward statistics, i.e. it streams three tensors of the output's size and is HBM-bound; timed that
+//     way (FUSED=1, profiles/r02_tune_conv_fused.txt) two workgroups per CU overlap one tile's epilogue with another's K loop and
+//     win for >= 512 columns and for 256 columns with K >= 128.
 // Returns the tile configuration, or -1 for the kernels that take fp32 weights.  BDVCIL_PL_TILE / bdv_conv_debug_force_tile
 // override the rules wherever the forced tile divides the column count.
-int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride, int pieces = 3) {
+int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride, int pieces = 3, bool shifted = false) {
   const int forced = pl_tile_override();
   if (pieces == 1)  // the single-product arithmetic only exists in the 8-wave kernels
     return forced >= 0 && forced < kNumPlCfg && ncols % kPlCfg[forced].BN == 0 ? forced
@@ -2600,6 +2673,7 @@ int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride, int pieces = 3)
   }
   if (stride == 2 && taps > 1) return -1;
   if (nk <= 8 && ncols >= 1024) return -1;
+  if (shifted && taps == 1 && (ncols >= 512 || nk >= 4)) return -1;
   return 2;
 }
 
@@ -2633,13 +2707,19 @@ bool r1_planes_enabled() {
   return on;
 }
 
+// the stem (Cin = 4) on the bf16-piece K loop (BDVCIL_C4_X3=0: on the fp32-MFMA kernel, as in round 1)
+bool c4_x3_enabled() {
+  static const bool on = getenv("BDVCIL_C4_X3") == nullptr || atoi(getenv("BDVCIL_C4_X3")) != 0;
+  return on;
+}
+
 int pl_fprop_cfg(const bdv_conv_geom* g, int pieces = 3) {
   if (g->Cin % BK != 0) return -1;
   return pl_pick(false, g->Cout, g->R * g->S * g->Cin / BK, g->R * g->S, g->stride, pieces);
 }
 int pl_dgrad_cfg(const bdv_conv_geom* g, int pieces = 3) {
   if (g->Cout % BK != 0) return -1;
-  return pl_pick(true, g->Cin, g->R * g->S * g->Cout / BK, g->R * g->S, g->stride, pieces);
+  return pl_pick(true, g->Cin, g->R * g->S * g->Cout / BK, g->R * g->S, g->stride, pieces, g->fold > 0);
 }
 bool pl_fprop_ok(const bdv_conv_geom* g, int pieces = 3) { return pl_fprop_cfg(g, pieces) >= 0; }
 bool pl_dgrad_ok(const bdv_conv_geom* g, int pieces = 3) { return pl_dgrad_cfg(g, pieces) >= 0; }
@@ -2688,24 +2768,43 @@ WgradPlan plan_wgrad(const bdv_conv_geom* g) {
   return p;
 }
 
-bool pl_wgrad_ok(const bdv_conv_geom* g) { return g->Cin % 128 == 0 && g->Cout % 128 == 0; }
+// Tile forms of conv_wgrad_pl_kernel: 0 = 128/256 x 128/256 (8 waves); the 64-channel layers: 1 = 64 x 192 (a filter row of
+// three taps x 64 input channels), 2 = 64 x 64 (1x1), 3 = 256 x 64 (1x1), 4 = 64 x 256 (1x1), 5 = the stem (Cin = 4 on NHWC4:
+// 64 x 256 = 64 taps of 4 channels, R*S <= 64, the columns past the last tap stay empty); -1 = not covered.
+int pl_wgrad_form(const bdv_conv_geom* g) {
+  static const bool small_on = getenv("BDVCIL_PL_WGRAD64") == nullptr || atoi(getenv("BDVCIL_PL_WGRAD64")) != 0;
+  const int RS = g->R * g->S;
+  if (g->Cin % 128 == 0 && g->Cout % 128 == 0) return 0;
+  if (!small_on) return -1;
+  if (g->Cout == 64 && g->Cin == 64) return RS % 3 == 0 ? 1 : RS == 1 ? 2 : -1;
+  if (g->Cout % 256 == 0 && g->Cin == 64 && RS == 1) return 3;
+  if (g->Cout == 64 && g->Cin % 256 == 0 && RS == 1) return 4;
+  if (g->Cout == 64 && g->Cin == 4 && RS <= 64 && c4_x3_enabled()) return 5;
+  return -1;
+}
+bool pl_wgrad_ok(const bdv_conv_geom* g) { return pl_wgrad_form(g) >= 0; }
 
 // wgrad of the P family: one workgroup per CU, tiles of 128 / 256 output channels x 128 / 256 input channels of a tap
 struct WgradPlPlan {
-  int BM, BN, MTw, NTw, splits, kt_per_split;
+  int form, BM, BN, MTw, NTw, splits, kt_per_split;
 };
 
 WgradPlPlan plan_wgrad_pl(const bdv_conv_geom* g) {
   WgradPlPlan p;
-  p.BM = g->Cout % 256 == 0 ? 256 : 128;
-  p.BN = g->Cin % 256 == 0 ? 256 : 128;
+  p.form = pl_wgrad_form(g);
+  static const int kBM[6] = {0, 64, 64, 256, 64, 64}, kBN[6] = {0, 192, 64, 64, 256, 256};
+  p.BM = p.form == 0 ? (g->Cout % 256 == 0 ? 256 : 128) : kBM[p.form];
+  p.BN = p.form == 0 ? (g->Cin % 256 == 0 ? 256 : 128) : kBN[p.form];
   p.MTw = g->Cout / p.BM;
-  p.NTw = g->R * g->S * (g->Cin / p.BN);
+  p.NTw = (g->R * g->S * g->Cin + p.BN - 1) / p.BN;
   const int64_t M = (int64_t)g->N * g->Ho * g->Wo;
   const int nkt = (int)((M + BK - 1) / BK);
   const int tiles = p.MTw * p.NTw;
-  const int W = 256;
-  const double t_iter = 2.7 * (double)(p.BM * p.BN) / (128.0 * 256.0);
+  const int W = p.form == 0 ? 256 : 512;   // the 4-wave forms run two workgroups per CU
+  // K-step of one workgroup, microseconds: MFMA-bound for the large tiles; the 64-channel layers are bound by streaming their
+  // operands from HBM (a K-step reads 32 x (BM + BN) floats; 256 CUs share ~5 TB/s)
+  const double t_iter = p.form == 0 ? 2.7 * (double)(p.BM * p.BN) / (128.0 * 256.0)
+                                    : fmax(2.7 * (double)(p.BM * p.BN) / (128.0 * 256.0) * 2.0, 32.0 * (p.BM + p.BN) * 4.0 * 2.0 / 20.0e3);
   const double dw_bytes = (double)g->Cout * g->R * g->S * g->Cin * 4.0;
   int best_s = 1;
   double best_cost = 1e30;
@@ -2801,7 +2900,12 @@ int conv_fprop_impl(const float* x, const float* w, float* y, const bdv_conv_geo
   if (debug_plan())
     fprintf(stderr, "[bdv plan] fprop %dx%d Cin %d Cout %d k%d s%d: tiles %d nk %d -> dp %d rem %d split %d\n", g.H, g.W,
             g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
-  if (c4) {
+  if (c4 && x3 && c4_x3_enabled()) {
+    if (p.wide)
+      hipLaunchKernelGGL((conv_fprop_c4_x3_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, epi);
+    else
+      hipLaunchKernelGGL((conv_fprop_c4_x3_kernel<128, 64, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, epi);
+  } else if (c4) {
     if (p.wide)
       hipLaunchKernelGGL((conv_fprop_c4_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, epi);
     else
@@ -2943,7 +3047,7 @@ extern "C" int bdv_conv_kernel_name(const bdv_conv_geom* gg, int kind, int arith
       const int wm = cfg == 0 || cfg == 2 ? 2 : 4;
       snprintf(out, n, "conv_fprop_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, wm, 8 / wm, kPlCfg[cfg].nbuf, arith == 2 ? 1 : 3);
     } else if (c4) {
-      snprintf(out, n, "conv_fprop_c4_kernel<128, %d, 2, 2>", gg->Cout % 128 == 0 ? 128 : 64);
+      snprintf(out, n, "conv_fprop_c4_%skernel<128, %d, 2, 2>", arith && c4_x3_enabled() ? "x3_" : "", gg->Cout % 128 == 0 ? 128 : 64);
     } else if (gg->Cout % 128 == 0 && arith) {
       snprintf(out, n, "conv_fprop_x3_kernel<128, 128, 2, 2, %s>", r1_planes_enabled() ? "true" : "false");
     } else {
@@ -3252,20 +3356,25 @@ extern "C" int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const 
     fprintf(stderr, "[bdv plan] wgrad_pl %dx%d Cin %d Cout %d k%d s%d: %dx%d tiles %d -> splits %d x %d k-iters\n", gg->H, gg->W, gg->Cin,
             gg->Cout, gg->R, gg->stride, p.BM, p.BN, p.MTw * p.NTw, p.splits, p.kt_per_split);
   const bool incr = g.Ho * g.Wo > BK && BK / g.Wo + 1 <= g.Ho;
-#define BDV_WGRAD_PL2(BM_, BN_, INCR_, NP_)                                                                                      \
-  hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, INCR_, NP_>), grid, dim3(512), 0, s, dy, x, (float*)slab, g, p.MTw, p.NTw,    \
-                     p.kt_per_split)
-#define BDV_WGRAD_PL(BM_, BN_)                                                                                                   \
+#define BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, INCR_, NP_, MTAP_)                                                                     \
+  hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, WM_, WN_, INCR_, NP_, MTAP_>), grid, dim3(64 * WM_ * WN_), 0, s, dy, x,      \
+                     (float*)slab, g, p.MTw, p.NTw, p.kt_per_split)
+#define BDV_WGRAD_PL(BM_, BN_, WM_, WN_, MTAP_)                                                                                  \
   do {                                                                                                                           \
-    if (incr && pieces == 3) BDV_WGRAD_PL2(BM_, BN_, true, 3);                                                                   \
-    else if (pieces == 3) BDV_WGRAD_PL2(BM_, BN_, false, 3);                                                                     \
-    else if (incr) BDV_WGRAD_PL2(BM_, BN_, true, 1);                                                                             \
-    else BDV_WGRAD_PL2(BM_, BN_, false, 1);                                                                                      \
+    if (incr && pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 3, MTAP_);                                                  \
+    else if (pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 3, MTAP_);                                                    \
+    else if (incr) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 1, MTAP_);                                                            \
+    else BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 1, MTAP_);                                                                     \
   } while (0)
-  if (p.BM == 256 && p.BN == 256) BDV_WGRAD_PL(256, 256);
-  else if (p.BM == 256) BDV_WGRAD_PL(256, 128);
-  else if (p.BN == 256) BDV_WGRAD_PL(128, 256);
-  else BDV_WGRAD_PL(128, 128);
+  if (p.form == 1) BDV_WGRAD_PL(64, 192, 2, 2, true);
+  else if (p.form == 2) BDV_WGRAD_PL(64, 64, 2, 2, false);
+  else if (p.form == 3) BDV_WGRAD_PL(256, 64, 4, 1, false);
+  else if (p.form == 4) BDV_WGRAD_PL(64, 256, 1, 4, false);
+  else if (p.form == 5) BDV_WGRAD_PL(64, 256, 1, 4, true);
+  else if (p.BM == 256 && p.BN == 256) BDV_WGRAD_PL(256, 256, 2, 4, false);
+  else if (p.BM == 256) BDV_WGRAD_PL(256, 128, 2, 4, false);
+  else if (p.BN == 256) BDV_WGRAD_PL(128, 256, 2, 4, false);
+  else BDV_WGRAD_PL(128, 128, 2, 4, false);
 #undef BDV_WGRAD_PL
 #undef BDV_WGRAD_PL2
   BDV_LAUNCH_CHECK("bdv_conv_wgrad_partial_pl");

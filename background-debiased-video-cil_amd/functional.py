@@ -78,14 +78,22 @@ class wgrad_batch:
 
     def __enter__(self):
         self.items, self.outer = [], wgrad_batch.current
-        if BATCH_WGRAD_REDUCE and not _SIDE['enabled']:
+        if BATCH_WGRAD_REDUCE:
             wgrad_batch.current = self
         return self
 
     def __exit__(self, exc_type, exc, tb):
         wgrad_batch.current = self.outer
         if exc_type is None and self.items:
-            K.wgrad_reduce_batched(self.items)
+            if _SIDE['enabled'] and self.items[0][0].is_cuda:     # the partial products were launched on the side stream
+                idx, side = _side_stream(self.items[0][0].device)
+                with torch.cuda.stream(side):
+                    K.wgrad_reduce_batched(self.items)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                _SIDE['pending'][idx] = done
+            else:
+                K.wgrad_reduce_batched(self.items)
         self.items = []
         return False
 
@@ -93,11 +101,12 @@ class wgrad_batch:
 def wgrad_overlapped(dy: torch.Tensor, inp: torch.Tensor, geom) -> torch.Tensor:
     """Weight gradient of one conv: deferred reduction inside a ``wgrad_batch``, otherwise K.conv_wgrad (optionally on the
     side stream)."""
-    if wgrad_batch.current is not None:
-        slab, dw = K.conv_wgrad_partial(dy, inp, geom)
-        wgrad_batch.current.items.append((slab, dw))
-        return dw
+    batch = wgrad_batch.current
     if not _SIDE['enabled']:
+        if batch is not None:
+            slab, dw = K.conv_wgrad_partial(dy, inp, geom)
+            batch.items.append((slab, dw))
+            return dw
         return K.conv_wgrad(dy, inp, geom)
     main = torch.cuda.current_stream(dy.device)
     idx, side = _side_stream(dy.device)
@@ -106,7 +115,11 @@ def wgrad_overlapped(dy: torch.Tensor, inp: torch.Tensor, geom) -> torch.Tensor:
     ready.record(main)
     side.wait_event(ready)
     with torch.cuda.stream(side):
-        K.conv_wgrad(dy, inp, geom, dw=dw, beta=0.0, ws_tag='wgrad_side')
+        if batch is not None:       # split-K slabs now, one reduction launch (on the side stream) when the stage ends
+            slab, _ = K.conv_wgrad_partial(dy, inp, geom, dw=dw)
+            batch.items.append((slab, dw))
+        else:
+            K.conv_wgrad(dy, inp, geom, dw=dw, beta=0.0, ws_tag='wgrad_side')
         done = torch.cuda.Event()
         done.record(side)
     for t in (dy, inp, dw):
