@@ -47,10 +47,19 @@ BATCH_WGRAD_REDUCE = _os.environ.get('BDVCIL_BATCH_WGRAD_REDUCE', '1') != '0'
 # Test hook: when set to a list, every training-mode forward appends the 1-bit ReLU masks it writes, in execution order
 # (stem, then per block: unit 0, unit 1, ..., block output); the parity tests compare them with the CPU reference's signs.
 RELU_MASK_TAP = None
+POOL_IDX_TAP = None      # tests: the stem max-pool's arg-max codes (3 r + s per output element), same purpose
 
 
 def set_side_stream_enabled(flag: bool):
     _SIDE['enabled'] = bool(flag)
+
+
+def side_stream_enabled() -> bool:
+    return _SIDE['enabled']
+
+
+def side_stream(device) -> torch.cuda.Stream:
+    return _side_stream(device)[1]
 
 
 def _side_stream(device):
@@ -263,6 +272,8 @@ class StemFn(torch.autograd.Function):
             p, idx, mask = K.bn_relu_maxpool_fwd(y, scale, shift)
             if RELU_MASK_TAP is not None:
                 RELU_MASK_TAP.append((tuple(y.shape), mask))
+            if POOL_IDX_TAP is not None:
+                POOL_IDX_TAP.append(idx)
             a_shape = tuple(y.shape)
         else:
             a = _conv_bn_eval(x4, w4, g, bn, gamma, beta, None, True)

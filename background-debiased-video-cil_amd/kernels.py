@@ -138,17 +138,38 @@ USE_PL = _os.environ.get('BDVCIL_PL', '1') != '0'       # 0: the round-1 bf16-pi
 USE_PL_WGRAD = _os.environ.get('BDVCIL_PL_WGRAD', '1') != '0'
 
 
-def bump_weight_epoch():
-    """Tell the plane cache that weights were changed behind torch's back (raw-pointer kernels)."""
+def bump_weight_epoch(params=None):
+    """Tell the plane cache that weights were changed behind torch's back (raw-pointer kernels): the given parameters, or
+    every cached weight when ``params`` is None (a frozen teacher's planes survive the student's optimizer steps)."""
     global WEIGHT_EPOCH
-    WEIGHT_EPOCH += 1
+    if params is None:
+        WEIGHT_EPOCH += 1
+        return
+    for p in params:
+        ent = _PLANES.get(id(p))
+        if ent is not None:
+            ent[1] = None
+
+
+_PLANES_PENDING = {}    # device index -> (event of the last refresh_weight_planes() on another stream, streams ordered behind it)
+
+
+def _plane_stamp(w, base):
+    return (w.data_ptr(), base._version, WEIGHT_EPOCH)
 
 
 def weight_planes(w: torch.Tensor, g: ConvGeom):
     """(planes_fprop, planes_dgrad) of the (Cout, R, S, Cin) weight view ``w``: uint8 views of one cached buffer."""
+    if _PLANES_PENDING:
+        pend = _PLANES_PENDING.get(w.device.index)
+        if pend is not None:                            # (event, stream ids that are ordered behind it already)
+            cur = torch.cuda.current_stream(w.device)
+            if cur.cuda_stream not in pend[1]:
+                cur.wait_event(pend[0])
+                pend[1].add(cur.cuda_stream)
     base = w._base if w._base is not None else w
     key = id(base)
-    stamp = (w.data_ptr(), base._version, WEIGHT_EPOCH)
+    stamp = _plane_stamp(w, base)
     ent = _PLANES.get(key)
     if ent is not None and ent[0]() is not base:
         ent = None                                      # the id was recycled by another tensor
@@ -161,9 +182,47 @@ def weight_planes(w: torch.Tensor, g: ConvGeom):
         check(lib().bdv_conv_split_weights(_p(w), ctypes.byref(g), _p(buf[:nbytes]), _p(buf[nbytes:]), _stream()),
               'bdv_conv_split_weights')
         ref = _weakref.ref(base, lambda _r, k=key: _PLANES.pop(k, None))
-        ent = [ref, stamp, buf]
+        # how to rebuild the view and the geometry without holding the parameter alive (refresh_weight_planes)
+        ent = [ref, stamp, buf, (tuple(w.shape), tuple(w.stride()), w.storage_offset()), (g.R, g.S, g.Cin, g.Cout)]
         _PLANES[key] = ent
     return ent[2][:nbytes], ent[2][nbytes:]
+
+
+def refresh_weight_planes(stream: Optional[torch.cuda.Stream] = None) -> int:
+    """Re-split every cached weight whose planes are stale (after an optimizer step) in one go, on ``stream`` (default: the
+    current one).  On another stream the work overlaps what the current stream does next (front-end, stem); the first
+    ``weight_planes`` call afterwards makes its stream wait for it.  Returns the number of weights re-split."""
+    n = 0
+    by_dev = {}
+    for key, ent in list(_PLANES.items()):
+        base = ent[0]()
+        if base is None or not base.is_cuda:
+            continue
+        shape, stride, off = ent[3]
+        w = base.as_strided(shape, stride, off) if (tuple(base.shape), tuple(base.stride())) != (shape, stride) else base
+        if ent[1] == _plane_stamp(w, base):
+            continue
+        by_dev.setdefault(base.device, []).append((ent, w, base))
+    for device, todo in by_dev.items():
+        cur = torch.cuda.current_stream(device)
+        st = stream if stream is not None and stream.device == device else cur
+        if st != cur:
+            st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            for ent, w, base in todo:
+                R, S, Cin, Cout = ent[4]
+                g = make_geom(1, R, S, Cin, Cout, R, S, 1, 0, 1, 0)
+                buf = ent[2]
+                nbytes = buf.numel() // 2
+                check(lib().bdv_conv_split_weights(_p(w), ctypes.byref(g), _p(buf[:nbytes]), _p(buf[nbytes:]), _stream()),
+                      'bdv_conv_split_weights')
+                ent[1] = _plane_stamp(w, base)
+                n += 1
+            if st != cur:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                _PLANES_PENDING[device.index] = (ev, {st.cuda_stream})
+    return n
 
 
 def conv_kernel_name(g: ConvGeom, kind: str, x3: Optional[bool] = None) -> str:

@@ -9,6 +9,7 @@
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -17,7 +18,7 @@ from torch.nn.modules.batchnorm import _BatchNorm
 from torch.nn.modules.conv import _ConvNd
 
 from . import kernels as K
-from .functional import join_side_stream
+from .functional import join_side_stream, side_stream, side_stream_enabled
 from .heads import LSC, IncrementalNet
 from .losses import LSCLoss
 from .registry import OPTIMIZER_BUILDERS, build_from_cfg
@@ -27,6 +28,9 @@ def _same_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
     """Same element order in memory: strides agree on every dimension longer than 1 (a 1x1 conv weight in
     channels_last order and its plainly contiguous parameter differ only in the strides of the size-1 dims)."""
     return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+
+
+PREFETCH_PLANES = os.environ.get('BDVCIL_PREFETCH_PLANES', '1') != '0'
 
 
 class FusedSGD(torch.optim.Optimizer):
@@ -132,7 +136,12 @@ class FusedSGD(torch.optim.Optimizer):
         t = self._build_tables(active)
         K.multi_sgd(t['p'], t['g'], t['b'], t['n'], t['lr'], t['wd'], len(active), momenta.pop(), self._grad_scale,
                     self._coef if self._clip_active else None)
-        K.bump_weight_epoch()        # the kernel updates the weights through raw pointers: cached bf16 planes are stale now
+        K.bump_weight_epoch([p for _, p in active])   # the kernel wrote these weights through raw pointers: their cached bf16 planes are stale
+        if PREFETCH_PLANES and side_stream_enabled():
+            # re-split them now, beside whatever the main stream does until the first conv of the next step needs them
+            dev = active[0][1].device
+            if dev.type == 'cuda':
+                K.refresh_weight_planes(side_stream(dev))
         self._clip_active = False
         return loss
 

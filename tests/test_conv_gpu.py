@@ -24,6 +24,8 @@ CASES = [
     (8, 7, 7, 256, 512, 3, 1, 1, 1, 0),       # several ci-blocks per tap, no shift
     (2, 32, 32, 4, 64, 7, 2, 3, 1, 0),        # stem 7x7 on NHWC4
     (3, 18, 22, 4, 64, 7, 2, 3, 1, 0),        # stem, non-square, ragged
+    (6, 9, 9, 64, 256, 1, 1, 0, 1, 0),        # layer-1 conv3 / downsample: 256 x 64 weight-gradient tile, ragged M (486 rows)
+    (16, 9, 9, 256, 64, 1, 1, 0, 8, 32),      # layer-1 conv1 (shift): 64 x 256 weight-gradient tile, ragged M
 ]
 
 
@@ -161,7 +163,7 @@ def test_dgrad_from_bf16_pieces(case, with_add, dev):
     assert torch.equal(K.conv_dgrad(dyd, wd, g, add_src=add.to(dev) if with_add else None, x3=True), d3)
 
 
-@pytest.mark.parametrize('case', [c for c in CASES if c[3] % 128 == 0 and c[4] % 128 == 0])
+@pytest.mark.parametrize('case', [c for c in CASES if c[3] % 64 == 0 or c[3] == 4])
 def test_wgrad_from_bf16_pieces(case, dev):
     """bdv_conv_wgrad_partial_x3 (the default arithmetic) + the batched reduction against the CPU reference and the fp32-MFMA kernel."""
     from bdvcil_amd import kernels as K
@@ -291,7 +293,8 @@ def test_split_weights_planes(shape, dev):
 
 def test_weight_plane_cache_follows_the_weights(dev):
     """The cached planes are refreshed when the weights change: through a torch in-place op (version counter), through the
-    fused SGD kernel (raw pointers: FusedSGD.step bumps the epoch), and not otherwise."""
+    fused SGD kernel (raw pointers: FusedSGD.step invalidates the parameters it stepped and re-splits them on the side stream),
+    through ``bump_weight_epoch()`` for any other raw write, and not otherwise."""
     import bdvcil_amd as bd
     from bdvcil_amd import functional as Fn
     from bdvcil_amd import kernels as K
@@ -307,11 +310,19 @@ def test_weight_plane_cache_follows_the_weights(dev):
     with torch.no_grad():
         wparam.mul_(2.0)                                                      # torch in-place op: version counter moves
     assert torch.equal(K.conv_fprop(x, Fn.weight_krsc(wparam), g, x3=True), 2 * y0)
+    frozen = torch.nn.Parameter(w0.contiguous(memory_format=torch.channels_last))          # a teacher's weight: never stepped
+    yf = K.conv_fprop(x, Fn.weight_krsc(frozen), g, x3=True)
+    stamp_frozen = K._PLANES[id(frozen)][1]
     opt = bd.FusedSGD([wparam], lr=0.5, momentum=0.0, weight_decay=0.0)
     wparam.grad = wparam.detach().clone()                                     # w <- w - 0.5 w: back to the first values
-    opt.step()
-    assert K.WEIGHT_EPOCH == epoch + 1
+    opt.step()                                                                # raw-pointer kernel: invalidates wparam's planes only
+    assert K.WEIGHT_EPOCH == epoch and K._PLANES[id(frozen)][1] is stamp_frozen
     assert torch.equal(K.conv_fprop(x, Fn.weight_krsc(wparam), g, x3=True), y0)
+    assert torch.equal(K.conv_fprop(x, Fn.weight_krsc(frozen), g, x3=True), yf)
+    wparam.data.mul_(3.0)                                                     # behind torch's back: needs the global bump
+    K.bump_weight_epoch()
+    assert K.WEIGHT_EPOCH == epoch + 1
+    assert torch.equal(K.conv_fprop(x, Fn.weight_krsc(wparam), g, x3=True), 3 * y0)
     key = id(wparam)
     del wparam, opt
     import gc

@@ -27,11 +27,10 @@ g = torch.Generator().manual_seed(1000)
 batch = dict(imgs=torch.randn(32, 8, 3, 224, 224, generator=g).to(dev), label=torch.randint(0, 101, (32, 1), generator=g).to(dev))
 
 VARIANTS = {
-    'one stream': dict(side=False, ds=False, prio=False),
-    'wgrad on side stream': dict(side=True, ds=False, prio=False),
-    'side + downsample branch on side': dict(side=True, ds=True, prio=False),
-    'side + main chain high priority': dict(side=True, ds=False, prio=True),
-    'side + ds + priority': dict(side=True, ds=True, prio=True),
+    'one stream': dict(side=False, ds=False, prio=False, batch=True),
+    'side streams (default)': dict(side=True, ds=True, prio=False, batch=True),
+    'side streams, split-K reduce per conv': dict(side=True, ds=True, prio=False, batch=False),
+    'side, downsample on main': dict(side=True, ds=False, prio=False, batch=True),
 }
 
 
@@ -39,6 +38,7 @@ def run(cfg, n):
     Fn.set_side_stream_enabled(cfg['side'])
     Fn.DS_SIDE = cfg['ds']
     CS._MAIN_HIGH_PRIORITY = cfg['prio']
+    Fn.BATCH_WGRAD_REDUCE = cfg['batch']
     for _ in range(2):
         engine.step(batch)
     torch.cuda.synchronize()

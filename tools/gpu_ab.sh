@@ -1,11 +1,11 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-step() {  # name, limit, command...
-  local name=$1 limit=$2; shift 2
-  timeout -k 10 $limit "$@" > gpurun_out/$name.log 2>&1
-  local rc=$?
-  echo "[$name] rc=$rc"
-  tail -n 8 gpurun_out/$name.log | cut -c1-330
-  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$name] killed at its limit: stopping"; exit $rc; fi
-}
-step ab_step 400 python tools/ab_step.py 3 10
+rm -f gpurun_out/parity_report.log
+timeout -k 10 1000 python -m pytest tests -m gpu -q --durations=5 > gpurun_out/pytest_gpu.log 2>&1
+rc=$?
+echo "[pytest_gpu] rc=$rc"; tail -n 5 gpurun_out/pytest_gpu.log
+if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "killed at its limit: stopping"; exit $rc; fi
+timeout -k 10 300 python bench.py --steps 12 --warmup 4 --no-cpu-baseline > gpurun_out/bench.log 2>&1
+echo "[bench] rc=$?"; tail -n 1 gpurun_out/bench.log | cut -c1-200
+BDVCIL_PREFETCH_PLANES=0 timeout -k 10 300 python bench.py --steps 12 --warmup 4 --no-cpu-baseline > gpurun_out/bench_nopf.log 2>&1
+echo "[bench_nopf] rc=$?"; tail -n 1 gpurun_out/bench_nopf.log | cut -c1-200
