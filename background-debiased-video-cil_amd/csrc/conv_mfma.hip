@@ -645,22 +645,41 @@ typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int X3_LDK = BK + 8;  // bf16 per LDS row: 80 bytes, the 16-byte fragment reads of 16 lanes cover all banks once
 
+// fp32 x 4 -> three bf16 pieces each, as packed pairs (x, y) and (z, w).  Written on pairs so that one v_cvt_pk_bf16_f32
+// converts two values, the leading piece is turned back into fp32 with a shift / a mask, and the remainders are taken with
+// v_pk_add_f32: 20 VALU per float4, where the element-wise __builtin_convertvector form compiles to 32.  The values are
+// the same bit for bit (round-to-nearest-even conversions, exact subtractions).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+__device__ __forceinline__ u32x2_t bf16_hi_pairs(const float4 v) { return (u32x2_t){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}; }
+__device__ __forceinline__ void split3_pairs(const float4 v, u32x2_t& hi, u32x2_t& mid, u32x2_t& lo) {
+  const unsigned h0 = pack_bf16x2(v.x, v.y), h1 = pack_bf16x2(v.z, v.w);
+  const float rx = v.x - __uint_as_float(h0 << 16), ry = v.y - __uint_as_float(h0 & 0xffff0000u);
+  const float rz = v.z - __uint_as_float(h1 << 16), rw = v.w - __uint_as_float(h1 & 0xffff0000u);
+  const unsigned m0 = pack_bf16x2(rx, ry), m1 = pack_bf16x2(rz, rw);
+  const float sx = rx - __uint_as_float(m0 << 16), sy = ry - __uint_as_float(m0 & 0xffff0000u);
+  const float sz = rz - __uint_as_float(m1 << 16), sw = rw - __uint_as_float(m1 & 0xffff0000u);
+  hi = (u32x2_t){h0, h1};
+  mid = (u32x2_t){m0, m1};
+  lo = (u32x2_t){pack_bf16x2(sx, sy), pack_bf16x2(sz, sw)};
+}
+
 // thread (row = tid / 8 + 32 p, k = 4 (tid % 8) .. + 3) -> planes[0 | 1 | 2][row][k]
 template <int ROWS, int P>
 __device__ __forceinline__ void store_split3(unsigned short* __restrict__ dst, const float4 (&v)[P], int tid) {
   const int arow = tid >> 3, kg = tid & 7;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    const f32x4_t a = {v[p].x, v[p].y, v[p].z, v[p].w};
-    const bf16x4_t hi = __builtin_convertvector(a, bf16x4_t);
-    const f32x4_t r1 = a - __builtin_convertvector(hi, f32x4_t);
-    const bf16x4_t mid = __builtin_convertvector(r1, bf16x4_t);
-    const f32x4_t r2 = r1 - __builtin_convertvector(mid, f32x4_t);
-    const bf16x4_t lo = __builtin_convertvector(r2, bf16x4_t);
+    u32x2_t hi, mid, lo;
+    split3_pairs(v[p], hi, mid, lo);
     unsigned short* q = dst + (arow + 32 * p) * X3_LDK + 4 * kg;
-    *reinterpret_cast<bf16x4_t*>(q) = hi;
-    *reinterpret_cast<bf16x4_t*>(q + ROWS * X3_LDK) = mid;
-    *reinterpret_cast<bf16x4_t*>(q + 2 * ROWS * X3_LDK) = lo;
+    *reinterpret_cast<u32x2_t*>(q) = hi;
+    *reinterpret_cast<u32x2_t*>(q + ROWS * X3_LDK) = mid;
+    *reinterpret_cast<u32x2_t*>(q + 2 * ROWS * X3_LDK) = lo;
   }
 }
 
@@ -1804,16 +1823,12 @@ __device__ __forceinline__ int pl_off(int row, int c) { return row * 64 + ((c ^ 
 
 // fp32 x 4 (row `row`, floats 4 kg .. 4 kg + 3 of the 32-deep step) -> hi / mid / lo planes of the stage image
 __device__ __forceinline__ void pl_split_store(unsigned char* __restrict__ base, int plane_bytes, int row, int kg, const float4 v) {
-  const f32x4_t a = {v.x, v.y, v.z, v.w};
-  const bf16x4_t hi = __builtin_convertvector(a, bf16x4_t);
-  const f32x4_t r1 = a - __builtin_convertvector(hi, f32x4_t);
-  const bf16x4_t mid = __builtin_convertvector(r1, bf16x4_t);
-  const f32x4_t r2 = r1 - __builtin_convertvector(mid, f32x4_t);
-  const bf16x4_t lo = __builtin_convertvector(r2, bf16x4_t);
+  u32x2_t hi, mid, lo;
+  split3_pairs(v, hi, mid, lo);
   unsigned char* q = base + pl_off(row, kg >> 1) + 8 * (kg & 1);
-  *reinterpret_cast<bf16x4_t*>(q) = hi;
-  *reinterpret_cast<bf16x4_t*>(q + plane_bytes) = mid;
-  *reinterpret_cast<bf16x4_t*>(q + 2 * plane_bytes) = lo;
+  *reinterpret_cast<u32x2_t*>(q) = hi;
+  *reinterpret_cast<u32x2_t*>(q + plane_bytes) = mid;
+  *reinterpret_cast<u32x2_t*>(q + 2 * plane_bytes) = lo;
 }
 
 // 32-deep K-step on one stage: wave (wm, wn) owns rows 32 WM i + 32 wm + r and columns 32 WN j + 32 wn + c (interleaved
@@ -1861,19 +1876,15 @@ __device__ __forceinline__ void mma_stage_pl(const unsigned char* __restrict__ A
 // fp32 x 4 -> the three planes (NP = 1: the leading one) of a stage image at the thread's precomputed byte offset
 template <int NP = 3>
 __device__ __forceinline__ void pl_split_store_at(unsigned char* __restrict__ q, int plane_bytes, const float4 v) {
-  const f32x4_t a = {v.x, v.y, v.z, v.w};
-  const bf16x4_t hi = __builtin_convertvector(a, bf16x4_t);
   if constexpr (NP == 1) {
-    *reinterpret_cast<bf16x4_t*>(q) = hi;
+    *reinterpret_cast<u32x2_t*>(q) = bf16_hi_pairs(v);
     return;
   }
-  const f32x4_t r1 = a - __builtin_convertvector(hi, f32x4_t);
-  const bf16x4_t mid = __builtin_convertvector(r1, bf16x4_t);
-  const f32x4_t r2 = r1 - __builtin_convertvector(mid, f32x4_t);
-  const bf16x4_t lo = __builtin_convertvector(r2, bf16x4_t);
-  *reinterpret_cast<bf16x4_t*>(q) = hi;
-  *reinterpret_cast<bf16x4_t*>(q + plane_bytes) = mid;
-  *reinterpret_cast<bf16x4_t*>(q + 2 * plane_bytes) = lo;
+  u32x2_t hi, mid, lo;
+  split3_pairs(v, hi, mid, lo);
+  *reinterpret_cast<u32x2_t*>(q) = hi;
+  *reinterpret_cast<u32x2_t*>(q + plane_bytes) = mid;
+  *reinterpret_cast<u32x2_t*>(q + 2 * plane_bytes) = lo;
 }
 
 // ---- weights -> bf16 planes ------------------------------------------------------------------
@@ -2243,20 +2254,16 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 template <int COLS, int NP = 3>
 __device__ __forceinline__ void pl_store_rows(unsigned char* __restrict__ base, int krow, int c4, const float4 v) {
   constexpr int PITCH = 2 * COLS + 64, PLANE = 32 * PITCH;
-  const f32x4_t a = {v.x, v.y, v.z, v.w};
-  const bf16x4_t hi = __builtin_convertvector(a, bf16x4_t);
   if constexpr (NP == 1) {
-    *reinterpret_cast<bf16x4_t*>(base + krow * PITCH + 8 * c4) = hi;
+    *reinterpret_cast<u32x2_t*>(base + krow * PITCH + 8 * c4) = bf16_hi_pairs(v);
     return;
   }
-  const f32x4_t r1 = a - __builtin_convertvector(hi, f32x4_t);
-  const bf16x4_t mid = __builtin_convertvector(r1, bf16x4_t);
-  const f32x4_t r2 = r1 - __builtin_convertvector(mid, f32x4_t);
-  const bf16x4_t lo = __builtin_convertvector(r2, bf16x4_t);
+  u32x2_t hi, mid, lo;
+  split3_pairs(v, hi, mid, lo);
   unsigned char* q = base + krow * PITCH + 8 * c4;
-  *reinterpret_cast<bf16x4_t*>(q) = hi;
-  *reinterpret_cast<bf16x4_t*>(q + PLANE) = mid;
-  *reinterpret_cast<bf16x4_t*>(q + 2 * PLANE) = lo;
+  *reinterpret_cast<u32x2_t*>(q) = hi;
+  *reinterpret_cast<u32x2_t*>(q + PLANE) = mid;
+  *reinterpret_cast<u32x2_t*>(q + 2 * PLANE) = lo;
 }
 
 // 8 k-values (pixels 16 s + 8 h .. + 7) of channel `cb + (lane & 31)` of plane image `p`

@@ -319,10 +319,10 @@ def test_weight_plane_cache_follows_the_weights(dev):
     assert K.WEIGHT_EPOCH == epoch and K._PLANES[id(frozen)][1] is stamp_frozen
     assert torch.equal(K.conv_fprop(x, Fn.weight_krsc(wparam), g, x3=True), y0)
     assert torch.equal(K.conv_fprop(x, Fn.weight_krsc(frozen), g, x3=True), yf)
-    wparam.data.mul_(3.0)                                                     # behind torch's back: needs the global bump
+    wparam.data.mul_(4.0)                                                     # behind torch's back: needs the global bump (x4: exact)
     K.bump_weight_epoch()
     assert K.WEIGHT_EPOCH == epoch + 1
-    assert torch.equal(K.conv_fprop(x, Fn.weight_krsc(wparam), g, x3=True), 3 * y0)
+    assert torch.equal(K.conv_fprop(x, Fn.weight_krsc(wparam), g, x3=True), 4 * y0)
     key = id(wparam)
     del wparam, opt
     import gc

@@ -65,7 +65,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // byte offset of 16-byte chunk c of row `row` in a plane image of 64-byte rows
 __device__ __forceinline__ int lds_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
 
-template <int BM, int BN, int WM, int WN, int NBUF, int PF, bool BPRE>
+template <int BM, int BN, int WM, int WN, int NBUF, int PF, bool BPRE, int ILV = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_x3p_kernel(const float* __restrict__ A, const float* __restrict__ B32,
                                                                const u16* __restrict__ Bp, float* __restrict__ C, int M, int N,
                                                                int K) {
@@ -112,16 +112,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_x3p_kernel(const float* __r
     }
   };
 
-  auto split_store = [&](unsigned char* base, int plane_bytes, int row, const f32x4 a) __attribute__((always_inline)) {
-    const bf16x4 hi = __builtin_convertvector(a, bf16x4);
-    const f32x4 r1 = a - __builtin_convertvector(hi, f32x4);
-    const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
-    const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
-    const bf16x4 lo = __builtin_convertvector(r2, bf16x4);
+  auto pk2 = [](float a, float b) __attribute__((always_inline)) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+  };
+  auto split_store = [&](unsigned char* base, int plane_bytes, int row, const f32x4 v) __attribute__((always_inline)) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const unsigned h0 = pk2(v.x, v.y), h1 = pk2(v.z, v.w);
+    const float rx = v.x - __uint_as_float(h0 << 16), ry = v.y - __uint_as_float(h0 & 0xffff0000u);
+    const float rz = v.z - __uint_as_float(h1 << 16), rw = v.w - __uint_as_float(h1 & 0xffff0000u);
+    const unsigned m0 = pk2(rx, ry), m1 = pk2(rz, rw);
+    const float sx = rx - __uint_as_float(m0 << 16), sy = ry - __uint_as_float(m0 & 0xffff0000u);
+    const float sz = rz - __uint_as_float(m1 << 16), sw = rw - __uint_as_float(m1 & 0xffff0000u);
     unsigned char* q = base + lds_off(row, kg >> 1) + 8 * (kg & 1);
-    *reinterpret_cast<bf16x4*>(q) = hi;
-    *reinterpret_cast<bf16x4*>(q + plane_bytes) = mid;
-    *reinterpret_cast<bf16x4*>(q + 2 * plane_bytes) = lo;
+    *reinterpret_cast<u32x2*>(q) = (u32x2){h0, h1};
+    *reinterpret_cast<u32x2*>(q + plane_bytes) = (u32x2){m0, m1};
+    *reinterpret_cast<u32x2*>(q + 2 * plane_bytes) = (u32x2){pk2(sx, sy), pk2(sz, sw)};
   };
 
   auto sstore = [&](int buf, auto set) __attribute__((always_inline)) {
@@ -209,7 +216,37 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_x3p_kernel(const float* __r
     if (nk > 1) gload(1, S1{});
     if (PF == 2 && nk > 2) gload(2, S0{});   // PF == 2: S0 was consumed by the store above
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
+    int kt0 = 0;
+    if constexpr (ILV > 0 && PF == 2) {
+      // steady state without conditions: MFMAs of step kt, split + store of step kt + 1 and the loads of step kt + 3 are ONE basic
+      // block, so the scheduler may interleave them (ILV == 2: pinned with sched_group_barrier)
+      constexpr int NM = TM * TN * 12, NDW = AP * 3 + 3 * BPP, NVM = AP + 3 * BPP;
+      constexpr int VPM = (AP * 22 + NM - 1) / NM;
+      auto pin = [&]() __attribute__((always_inline)) {
+        if constexpr (ILV == 2) {
+#pragma unroll
+          for (int g = 0; g < NM; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+            if (g % (NM / NDW) == 0 && g / (NM / NDW) < NDW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (g % (NM / NVM) == 1 && g / (NM / NVM) < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+        }
+      };
+      for (; kt0 + 4 < nk; kt0 += 2) {
+        mma(0);
+        sstore(1, S1{});
+        gload(kt0 + 3, S1{});
+        pin();
+        __syncthreads();
+        mma(1);
+        sstore(0, S0{});
+        gload(kt0 + 4, S0{});
+        pin();
+        __syncthreads();
+      }
+    }
+    for (int kt = kt0; kt < nk; kt += 2) {
       // even step: MFMAs on stage 0; registers of step kt + 1 sit in set S1
       if (PF == 1 && kt + 1 < nk && kt > 0) gload(kt + 1, S1{});
       mma(0);
@@ -248,14 +285,14 @@ struct Ctx {
   int nrows;
 };
 
-template <int BM, int BN, int WM, int WN, int NBUF, int PF, bool BPRE>
+template <int BM, int BN, int WM, int WN, int NBUF, int PF, bool BPRE, int ILV = 0>
 static void run(const char* name, const Ctx& c) {
   if (c.M % BM || c.N % BN) return;
   if (NBUF == 2 && PF == 1 && false) return;
   const dim3 grid((c.M / BM) * (c.N / BN));
   const size_t lds = (size_t)NBUF * 3 * (BM + BN) * 64;
   if (lds > 160 * 1024) return;
-  auto kern = gemm_x3p_kernel<BM, BN, WM, WN, NBUF, PF, BPRE>;
+  auto kern = gemm_x3p_kernel<BM, BN, WM, WN, NBUF, PF, BPRE, ILV>;
   CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   CHECK(hipMemset(c.dC, 0, (size_t)c.M * c.N * 4));
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, 0, c.dA, c.dB32, c.dBp, c.dC, c.M, c.N, c.K);
@@ -329,6 +366,11 @@ static void bench_shape(int M, int N, int K) {
   run<256, 256, 2, 4, 1, 1, true>("256x256 8w 1buf pf1 B pre-split", c);
   run<256, 256, 2, 4, 1, 2, true>("256x256 8w 1buf pf2 B pre-split", c);
   run<128, 256, 2, 4, 2, 2, false>("128x256 8w 2buf pf2 B split in loop", c);
+  run<128, 256, 2, 4, 2, 2, true, 1>("128x256 8w 2buf pf2 peeled", c);
+  run<128, 256, 2, 4, 2, 2, true, 2>("128x256 8w 2buf pf2 peeled + pinned interleave", c);
+  run<256, 128, 4, 2, 2, 2, true, 1>("256x128 8w 2buf pf2 peeled", c);
+  run<256, 128, 4, 2, 2, 2, true, 2>("256x128 8w 2buf pf2 peeled + pinned interleave", c);
+  run<128, 128, 2, 2, 2, 2, true, 2>("128x128 4w 2buf pf2 peeled + pinned interleave", c);
   CHECK(hipFree(dA));
   CHECK(hipFree(dB32));
   CHECK(hipFree(dBp));
