@@ -1929,6 +1929,44 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
   }
 }
 
+// Two LDS stages, two register sets, one barrier per K-step.  While the MFMAs of step i read stage i & 1, the registers of step
+// i + 1 (loaded during step i - 1) are split and stored into the other stage and the loads of step i + 3 are issued.  The
+// steady state is free of conditions, so a step's MFMAs, stores and loads are one basic block the scheduler can interleave
+// (tools/ubench/gemm_x3p.hip: 196 -> 215 TFLOP/s on a large GEMM, 159 -> 175 on the 3x3 256-channel site against the form with
+// one register set and `if (kt + 1 < ke)` around every store).  n = number of K-steps; load(set) loads the NEXT step in order.
+using PlSet0 = std::integral_constant<int, 0>;
+using PlSet1 = std::integral_constant<int, 1>;
+template <typename LoadF, typename StoreF, typename MmaF>
+__device__ __forceinline__ void pl_pipeline2(int n, LoadF&& load, StoreF&& store, MmaF&& mma) {
+  load(PlSet0{});
+  store(0, PlSet0{});
+  if (n > 1) load(PlSet1{});
+  if (n > 2) load(PlSet0{});
+  __syncthreads();
+  int i = 0;
+  for (; i + 4 < n; i += 2) {
+    mma(0);
+    store(1, PlSet1{});
+    load(PlSet1{});
+    __syncthreads();
+    mma(1);
+    store(0, PlSet0{});
+    load(PlSet0{});
+    __syncthreads();
+  }
+  for (; i < n; i += 2) {
+    mma(0);
+    if (i + 1 < n) store(1, PlSet1{});
+    if (i + 3 < n) load(PlSet1{});
+    __syncthreads();
+    if (i + 1 >= n) break;
+    mma(1);
+    if (i + 2 < n) store(0, PlSet0{});
+    if (i + 4 < n) load(PlSet0{});
+    __syncthreads();
+  }
+}
+
 // ---- fprop ------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int NBUF, int NP = 3>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_kernel(const float* __restrict__ x,
@@ -1987,9 +2025,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
     s = tap - r * g.S;
   }
 
-  float4 ra[AP];
-  u32x4 rb[NP * BPP];
-  auto load = [&]() {
+  constexpr int NSET = NBUF;           // two stages: two register sets (pl_pipeline2)
+  float4 ra[NSET][AP];
+  u32x4 rb[NSET][NP * BPP];
+  auto load = [&](auto set) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set)::value;
     const int cls = shift_class(chunk * BK + 4 * kg, g.fold);
     const int koff_a = ((r * g.W + s) * g.Cin + chunk * BK) * 4;
     const int koff_b = kt_w * g.Cout * 64;
@@ -1997,12 +2037,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
     for (int p = 0; p < AP; ++p) {
       const bool v = (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W &&
                      (unsigned)(a_t[p] + cls) < (unsigned)g.T;
-      ra[p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB), 0);
+      ra[SET][p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB), 0);
     }
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-      for (int q = 0; q < BPP; ++q) rb[pl * BPP + q] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_base[q] + pl * plane_bytes, koff_b, 0);
+      for (int q = 0; q < BPP; ++q) rb[SET][pl * BPP + q] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_base[q] + pl * plane_bytes, koff_b, 0);
     kt_w += 1;
     s += 1;
     const int ws_ = (s == g.S) ? 1 : 0;
@@ -2016,46 +2056,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
   const int st_a = pl_off(arow, kg >> 1) + 8 * (kg & 1), st_b = pl_off(brow, bc);
   const int fa[2] = {pl_frag_off(32 * wm, 0, lane), pl_frag_off(32 * wm, 1, lane)};
   const int fb[2] = {pl_frag_off(32 * wn, 0, lane), pl_frag_off(32 * wn, 1, lane)};
-  auto store = [&](int stage) {
+  auto store = [&](int stage, auto set) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set)::value;
     unsigned char* const As = smem_b + stage * STAGE;
     unsigned char* const Bs = As + 3 * PA;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) pl_split_store_at<NP>(As + st_a + (NTHR / 8) * p * 64, PA, ra[p]);
+    for (int p = 0; p < AP; ++p) pl_split_store_at<NP>(As + st_a + (NTHR / 8) * p * 64, PA, ra[SET][p]);
     if (b_active) {
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-        for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + st_b + (pl * PB + (NTHR / 4) * q * 64)) = rb[pl * BPP + q];
+        for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + st_b + (pl * PB + (NTHR / 4) * q * 64)) = rb[SET][pl * BPP + q];
     }
   };
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
 
   if constexpr (NBUF == 2) {
-    int kt = it.kb;
-    load();
-    store(0);
-    if (kt + 1 < it.ke) load();
-    __syncthreads();
-    while (true) {
-      mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + 3 * PA, acc, fa, fb);
-      if (kt + 1 < it.ke) store(1);
-      if (kt + 2 < it.ke) load();
-      __syncthreads();
-      if (++kt >= it.ke) break;
-      mma_stage_pl<BM, BN, WM, WN, NP>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, fa, fb);
-      if (kt + 1 < it.ke) store(0);
-      if (kt + 2 < it.ke) load();
-      __syncthreads();
-      if (++kt >= it.ke) break;
-    }
+    pl_pipeline2(it.ke - it.kb, load, store, [&](int stage) __attribute__((always_inline)) {
+      mma_stage_pl<BM, BN, WM, WN, NP>(smem_b + stage * STAGE, smem_b + stage * STAGE + 3 * PA, acc, fa, fb);
+    });
   } else {
-    load();
+    load(PlSet0{});
     for (int kt = it.kb; kt < it.ke; ++kt) {
       __syncthreads();
-      store(0);
+      store(0, PlSet0{});
       __syncthreads();
-      if (kt + 1 < it.ke) load();
+      if (kt + 1 < it.ke) load(PlSet0{});
       mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + 3 * PA, acc, fa, fb);
     }
   }
@@ -2155,21 +2182,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
   }
   const int nchunk = g.Cout / BK;
 
-  float4 ra[AP];
-  u32x4 rb[NP * BPP];
-  auto load = [&]() {
+  constexpr int NSET = NBUF;
+  float4 ra[NSET][AP];
+  u32x4 rb[NSET][NP * BPP];
+  auto load = [&](auto set) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set)::value;
     const int tap = (r0 + ir * st) * g.S + (s0 + is * st);
     const int koff_a = (chunk * BK - (ir * g.Wo + is) * g.Cout) * 4;
     const int koff_b = (tap * nchunk + chunk) * g.Cin * 64;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       const bool v = (unsigned)(a_h[p] - ir) < (unsigned)g.Ho && (unsigned)(a_w[p] - is) < (unsigned)g.Wo;
-      ra[p] = buf_load16(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB), 0);
+      ra[SET][p] = buf_load16(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB), 0);
     }
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-      for (int q = 0; q < BPP; ++q) rb[pl * BPP + q] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_base[q] + pl * plane_bytes, koff_b, 0);
+      for (int q = 0; q < BPP; ++q) rb[SET][pl * BPP + q] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_base[q] + pl * plane_bytes, koff_b, 0);
     is += 1;
     const int w1 = (is == ns) ? 1 : 0;
     is = w1 ? 0 : is;
@@ -2182,16 +2211,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
   const int st_a = pl_off(arow, kg >> 1) + 8 * (kg & 1), st_b = pl_off(brow, bc);
   const int fa[2] = {pl_frag_off(32 * wm, 0, lane), pl_frag_off(32 * wm, 1, lane)};
   const int fb[2] = {pl_frag_off(32 * wn, 0, lane), pl_frag_off(32 * wn, 1, lane)};
-  auto store = [&](int stage) {
+  auto store = [&](int stage, auto set) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set)::value;
     unsigned char* const As = smem_b + stage * STAGE;
     unsigned char* const Bs = As + 3 * PA;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) pl_split_store_at<NP>(As + st_a + (NTHR / 8) * p * 64, PA, ra[p]);
+    for (int p = 0; p < AP; ++p) pl_split_store_at<NP>(As + st_a + (NTHR / 8) * p * 64, PA, ra[SET][p]);
     if (b_active) {
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-        for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + st_b + (pl * PB + (NTHR / 4) * q * 64)) = rb[pl * BPP + q];
+        for (int q = 0; q < BPP; ++q) *reinterpret_cast<u32x4*>(Bs + st_b + (pl * PB + (NTHR / 4) * q * 64)) = rb[SET][pl * BPP + q];
     }
   };
 
@@ -2200,30 +2230,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
 
   if (it.ke > it.kb) {
     if constexpr (NBUF == 2) {
-      int kt = it.kb;
-      load();
-      store(0);
-      if (kt + 1 < it.ke) load();
-      __syncthreads();
-      while (true) {
-        mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + 3 * PA, acc, fa, fb);
-        if (kt + 1 < it.ke) store(1);
-        if (kt + 2 < it.ke) load();
-        __syncthreads();
-        if (++kt >= it.ke) break;
-        mma_stage_pl<BM, BN, WM, WN, NP>(smem_b + STAGE, smem_b + STAGE + 3 * PA, acc, fa, fb);
-        if (kt + 1 < it.ke) store(0);
-        if (kt + 2 < it.ke) load();
-        __syncthreads();
-        if (++kt >= it.ke) break;
-      }
+      pl_pipeline2(it.ke - it.kb, load, store, [&](int stage) __attribute__((always_inline)) {
+        mma_stage_pl<BM, BN, WM, WN, NP>(smem_b + stage * STAGE, smem_b + stage * STAGE + 3 * PA, acc, fa, fb);
+      });
     } else {
-      load();
+      load(PlSet0{});
       for (int kt = it.kb; kt < it.ke; ++kt) {
         __syncthreads();
-        store(0);
+        store(0, PlSet0{});
         __syncthreads();
-        if (kt + 1 < it.ke) load();
+        if (kt + 1 < it.ke) load(PlSet0{});
         mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + 3 * PA, acc, fa, fb);
       }
     }
@@ -2649,18 +2665,19 @@ int pl_tile_override() {
 }
 
 // M = GEMM rows, ncols = GEMM columns (Cout for fprop, Cin for dgrad), nk = 32-deep K-steps; ksplit_ok: stride-1 launches only
-// Which kernel family runs a site.  Rules read off tools/tune_conv.py (every choice timed per TSM-R50 site in one process,
-// profiles/r02_tune_conv.txt); differences between neighbouring choices are a few per cent, the rules keep the clear ones:
-//   * 128 output columns: the two-workgroups-per-CU kernels (conv_*_x3_kernel) -- a 256x128 tile never beat them;
+// Which kernel family runs a site.  Rules read off tools/tune_conv.py (every choice timed per TSM-R50 site in one process, with
+// the training step's fused epilogues: profiles/r02_tune_conv_fused.txt; plain calls: profiles/r02_tune_conv.txt); differences
+// between neighbouring choices are a few per cent, the rules keep the clear ones:
 //   * 64 output columns: 256x64 tiles for 3x3 filters (compute-bound: +16 %), the fp32-MFMA 64-wide kernels for 1x1 (HBM-bound);
-//   * multiples of 256 columns: fprop 256x256 tiles when there are exactly 256 columns and K >= 512, else 128x256 tiles for
-//     K >= 512 or K = 64, else the x3 kernels (K = 128 / 256: eight or fewer K-steps cannot hide an 8-wave workgroup's
-//     prologue and epilogue, two smaller workgroups per CU can); dgrad 256x256 tiles except for short K with >= 1024 columns
-//     and for stride-2 3x3 filters (four parity classes with a quarter of the taps each);
-//   * dgrad of a block's conv1 (1x1 with the temporal shift): in the training step its epilogue adds the identity-branch gradient
-//     and takes the BatchNorm-backward statistics, i.e. it streams three tensors of the output's size and is HBM-bound; timed that
-//     way (FUSED=1, profiles/r02_tune_conv_fused.txt) two workgroups per CU overlap one tile's epilogue with another's K loop and
-//     win for >= 512 columns and for 256 columns with K >= 128.
+//   * 128 output columns: 256x128 tiles when K >= 512 (fprop) / for stride-1 3x3 filters (dgrad), else the two-workgroups-per-CU
+//     kernels (conv_*_x3_kernel): eight or fewer K-steps cannot hide an 8-wave workgroup's prologue and epilogue;
+//   * multiples of 256 columns, fprop: 128x256 tiles (two stages, pl_pipeline2) for K >= 512 or K = 64, else the x3 kernels;
+//   * multiples of 256 columns, dgrad: 256x256 tiles, except 128x256 for stride-2 3x3 filters (four parity classes with a quarter
+//     of the taps each: more, smaller tiles) and for 512 columns with K >= 2048; the x3 kernels for short K with >= 1024 columns
+//     and for a block's conv1 (1x1 with the temporal shift): in the training step its epilogue adds the identity-branch gradient
+//     and takes the BatchNorm-backward statistics, i.e. it streams three tensors of the output's size and is HBM-bound; two
+//     workgroups per CU overlap one tile's epilogue with another's K loop and win for >= 512 columns and for 256 columns with
+//     K >= 128.
 // Returns the tile configuration, or -1 for the kernels that take fp32 weights.  BDVCIL_PL_TILE / bdv_conv_debug_force_tile
 // override the rules wherever the forced tile divides the column count.
 int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride, int pieces = 3, bool shifted = false) {
@@ -2672,15 +2689,16 @@ int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride, int pieces = 3,
   if (forced >= 0 && ncols % kPlCfg[forced].BN == 0) return forced;
   if (ncols % 64 != 0) return -1;
   if (ncols % 128 != 0) return taps > 1 ? 3 : -1;
-  if (ncols % 256 != 0) return -1;
   if (!dgrad) {
-    if (ncols == 256 && nk >= 16) return 2;
+    if (ncols % 256 != 0) return nk >= 16 ? 1 : -1;
     if (nk >= 16 || nk <= 2) return 0;
     return -1;
   }
-  if (stride == 2 && taps > 1) return -1;
+  if (ncols % 256 != 0) return taps > 1 && stride == 1 ? 1 : -1;
+  if (stride == 2 && taps > 1) return 0;
   if (nk <= 8 && ncols >= 1024) return -1;
   if (shifted && taps == 1 && (ncols >= 512 || nk >= 4)) return -1;
+  if (ncols == 512 && nk >= 64) return 0;
   return 2;
 }
 
