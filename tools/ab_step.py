@@ -29,8 +29,8 @@ batch = dict(imgs=torch.randn(32, 8, 3, 224, 224, generator=g).to(dev), label=to
 VARIANTS = {
     'one stream': dict(side=False, ds=False, prio=False, batch=True),
     'side streams (default)': dict(side=True, ds=True, prio=False, batch=True),
-    'side streams, split-K reduce per conv': dict(side=True, ds=True, prio=False, batch=False),
-    'side, downsample on main': dict(side=True, ds=False, prio=False, batch=True),
+    'side streams, plain BN loads': dict(side=True, ds=True, prio=False, batch=True, nt=0),
+    'side streams, BN loads non-temporal except the residual': dict(side=True, ds=True, prio=False, batch=True, nt=1),
 }
 
 
@@ -39,6 +39,7 @@ def run(cfg, n):
     Fn.DS_SIDE = cfg['ds']
     CS._MAIN_HIGH_PRIORITY = cfg['prio']
     Fn.BATCH_WGRAD_REDUCE = cfg['batch']
+    os.environ['BDVCIL_BN_NT'] = str(cfg.get('nt', 2))
     for _ in range(2):
         engine.step(batch)
     torch.cuda.synchronize()
