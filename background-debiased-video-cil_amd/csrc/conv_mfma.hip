@@ -2267,9 +2267,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_ker
 // Eight waves (2 x 4), one workgroup per CU, one LDS stage.
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
-template <int COLS, int NP = 3>
+template <int COLS, int NP = 3, int ROWS = 32>
 __device__ __forceinline__ void pl_store_rows(unsigned char* __restrict__ base, int krow, int c4, const float4 v) {
-  constexpr int PITCH = 2 * COLS + 64, PLANE = 32 * PITCH;
+  constexpr int PITCH = 2 * COLS + 64, PLANE = ROWS * PITCH;
   if constexpr (NP == 1) {
     *reinterpret_cast<u32x2_t*>(base + krow * PITCH + 8 * c4) = bf16_hi_pairs(v);
     return;
@@ -2298,7 +2298,11 @@ __device__ __forceinline__ bf16x8_t pl_frag_tr(const unsigned char* __restrict__
 
 // MTAP: the BN columns of a tile span BN / Cin whole filter taps (64-channel layers: a 3x3 filter row = 192 columns).
 // WM x WN waves; the 4-wave forms (64-wide tiles, 60-72 KB of LDS) run two workgroups per CU.
-template <int BM, int BN, int WM, int WN, bool INCR, int NP = 3, bool MTAP = false>
+// KW = pixels per LDS stage.  32: one stage, two barriers per step (load -> barrier -> split + store -> barrier -> MFMAs).
+// 16: two stages of 16 pixels in the same LDS and two register sets, pl_pipeline2: the split + store of the next 16 pixels and the
+// loads of the ones after are issued among the MFMAs of the current stage, one barrier per 16 pixels -- for the tiles with at
+// least 24 MFMAs per wave and stage.
+template <int BM, int BN, int WM, int WN, bool INCR, int NP = 3, bool MTAP = false, int KW = 32>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                          float* __restrict__ slab, Geom g, int MTw, int NTw,
                                                                          int kt_per_split) {
@@ -2306,12 +2310,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(TM >= 1 && TN >= 1 && (32 * (BM / 4)) % NTHR == 0 && (32 * (BN / 4)) % NTHR == 0, "tile / thread mapping");
   constexpr int AV = BM / 4, BV = BN / 4;
-  constexpr int AP = 32 * AV / NTHR, BP = 32 * BV / NTHR;
+  static_assert(KW == 32 || KW == 16, "pixels per stage");
+  constexpr int NST = 32 / KW;          // LDS stages = register sets
+  constexpr int AP = KW * AV / NTHR, BP = KW * BV / NTHR;
+  static_assert(AP >= 1 && BP >= 1 && (KW * AV) % NTHR == 0 && (KW * BV) % NTHR == 0, "stage / thread mapping");
   constexpr int PITCH_A = 2 * BM + 64, PITCH_B = 2 * BN + 64;
-  constexpr int PLANE_A = 32 * PITCH_A, PLANE_B = 32 * PITCH_B;
-  __shared__ __attribute__((aligned(16))) unsigned char smem_b[3 * (PLANE_A + PLANE_B)];
-  unsigned char* const As = smem_b;
-  unsigned char* const Bs = smem_b + 3 * PLANE_A;
+  constexpr int PLANE_A = KW * PITCH_A, PLANE_B = KW * PITCH_B;
+  constexpr int STAGE = 3 * (PLANE_A + PLANE_B);
+  __shared__ __attribute__((aligned(16))) unsigned char smem_b[NST * STAGE];
 
   // slice-major, XCD-contiguous work order: all tiles of one K slice read the same rows of dy and x (see conv_wgrad_kernel)
   const int tiles = MTw * NTw;
@@ -2350,13 +2356,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
     b_off[p] = ((b_r[p] * g.W + b_s[p]) * g.Cin + ci) * 4 + b_cls[p] * frame_bytes;
   }
 
-  const int kt_begin = split * kt_per_split;
-  const int nkt_all = (g.M + BK - 1) / BK;
-  const int kt_end = min(kt_begin + kt_per_split, nkt_all);
+  // kt counts KW-pixel steps (kt_per_split is given in 32-pixel steps)
+  const int kt_begin = split * kt_per_split * NST;
+  const int nkt_all = (g.M + KW - 1) / KW;
+  const int kt_end = min(kt_begin + kt_per_split * NST, nkt_all);
 
   // incremental pixel state per B row (see conv_wgrad_kernel): no division in the loop
   const int st = g.stride;
-  const int d_ho = BK / g.Wo, d_wo = BK - d_ho * g.Wo;
+  const int d_ho = KW / g.Wo, d_wo = KW - d_ho * g.Wo;
   const int wrap_w = g.Wo * st, wrap_h = g.Ho * st;
   const int px = g.Cin * 4;
   const int inc0 = (d_ho * st * g.W + d_wo * st) * px;
@@ -2366,7 +2373,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
   if (INCR) {
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
-      const int m = split * kt_per_split * BK + b_krow[p];
+      const int m = kt_begin * KW + b_krow[p];
       const int n = m / HoWo;
       const int rem = m - n * HoWo;
       const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
@@ -2377,12 +2384,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
     }
   }
 
-  float4 ra[AP], rb[BP];
-  auto load = [&](int kt) {
-    const int m0 = kt * BK;
+  float4 ra[NST][AP], rb[NST][BP];
+  int kt_load = kt_begin;           // load(set) fetches the next step in order
+  auto load = [&](auto set) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set)::value;
+    const int m0 = kt_load * KW;
+    kt_load += 1;
 #pragma unroll
     for (int p = 0; p < AP; ++p)  // rows past M lie past num_records: zeros
-      ra[p] = buf_load16(yr, a_off[p] + m0 * g.Cout * 4, 0);
+      ra[SET][p] = buf_load16(yr, a_off[p] + m0 * g.Cout * 4, 0);
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
       const int m = m0 + b_krow[p];
@@ -2414,46 +2424,64 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
       }
       const bool v = mok && (unsigned)(hi + b_r[p]) < (unsigned)g.H && (unsigned)(wi_ + b_s[p]) < (unsigned)g.W &&
                      (unsigned)(t + b_cls[p]) < (unsigned)g.T;
-      rb[p] = buf_load16(xr, off | (v ? 0 : kOOB), 0);
+      rb[SET][p] = buf_load16(xr, off | (v ? 0 : kOOB), 0);
     }
   };
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
 
-  if (kt_begin < kt_end) {
-    load(kt_begin);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      __syncthreads();
+  auto store = [&](int stage, auto set) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set)::value;
+    unsigned char* const As = smem_b + stage * STAGE;
+    unsigned char* const Bs = As + 3 * PLANE_A;
 #pragma unroll
-      for (int p = 0; p < AP; ++p) pl_store_rows<BM, NP>(As, a_krow[p], (tid + NTHR * p) % AV, ra[p]);
+    for (int p = 0; p < AP; ++p) pl_store_rows<BM, NP, KW>(As, a_krow[p], (tid + NTHR * p) % AV, ra[SET][p]);
 #pragma unroll
-      for (int p = 0; p < BP; ++p) pl_store_rows<BN, NP>(Bs, b_krow[p], (tid + NTHR * p) % BV, rb[p]);
-      __syncthreads();
-      if (kt + 1 < kt_end) load(kt + 1);
+    for (int p = 0; p < BP; ++p) pl_store_rows<BN, NP, KW>(Bs, b_krow[p], (tid + NTHR * p) % BV, rb[SET][p]);
+  };
+  auto mma = [&](int stage) __attribute__((always_inline)) {
+    const unsigned char* const As = smem_b + stage * STAGE;
+    const unsigned char* const Bs = As + 3 * PLANE_A;
 #pragma unroll
-      for (int s = 0; s < BK / 16; ++s) {
-        bf16x8_t a[NP][TM], b[NP][TN];
+    for (int s = 0; s < KW / 16; ++s) {
+      // the column fragments of the 16-deep step stay in registers, the row fragments are fetched one 32-row tile at a time
+      // (all of them at once are 72 VGPRs for a 256 x 256 tile: with two register sets of loads that spills)
+      bf16x8_t b[NP][TN];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a[p][i] = pl_frag_tr<BM>(As + p * PLANE_A, 32 * WM * i + 32 * wm, s, lane);
+        for (int j = 0; j < TN; ++j) b[p][j] = pl_frag_tr<BN>(Bs + p * PLANE_B, 32 * WN * j + 32 * wn, s, lane);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) b[p][j] = pl_frag_tr<BN>(Bs + p * PLANE_B, 32 * WN * j + 32 * wn, s, lane);
-        }
+      for (int i = 0; i < TM; ++i) {
+        bf16x8_t a[NP];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int p = 0; p < NP; ++p) a[p] = pl_frag_tr<BM>(As + p * PLANE_A, 32 * WM * i + 32 * wm, s, lane);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if constexpr (NP == 3) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
-            }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (NP == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0][j], acc[i][j], 0, 0, 0);
           }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  };
+  if (kt_begin < kt_end) {
+    if constexpr (NST == 2) {
+      pl_pipeline2(kt_end - kt_begin, load, store, mma);
+    } else {
+      load(PlSet0{});
+      for (int kt = kt_begin; kt < kt_end; ++kt) {
+        __syncthreads();
+        store(0, PlSet0{});
+        __syncthreads();
+        if (kt + 1 < kt_end) load(PlSet0{});
+        mma(0);
       }
     }
   }
@@ -2796,6 +2824,12 @@ WgradPlan plan_wgrad(const bdv_conv_geom* g) {
 // Tile forms of conv_wgrad_pl_kernel: 0 = 128/256 x 128/256 (8 waves); the 64-channel layers: 1 = 64 x 192 (a filter row of
 // three taps x 64 input channels), 2 = 64 x 64 (1x1), 3 = 256 x 64 (1x1), 4 = 64 x 256 (1x1), 5 = the stem (Cin = 4 on NHWC4:
 // 64 x 256 = 64 taps of 4 channels, R*S <= 64, the columns past the last tap stay empty); -1 = not covered.
+// BDVCIL_WGRAD_2STAGE=0: the one-stage weight-gradient loop for every tile (read per call: A/B runs flip it)
+bool wgrad_two_stage() {
+  const char* e = getenv("BDVCIL_WGRAD_2STAGE");
+  return e == nullptr || atoi(e) != 0;
+}
+
 int pl_wgrad_form(const bdv_conv_geom* g) {
   static const bool small_on = getenv("BDVCIL_PL_WGRAD64") == nullptr || atoi(getenv("BDVCIL_PL_WGRAD64")) != 0;
   const int RS = g->R * g->S;
@@ -3381,25 +3415,29 @@ extern "C" int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const 
     fprintf(stderr, "[bdv plan] wgrad_pl %dx%d Cin %d Cout %d k%d s%d: %dx%d tiles %d -> splits %d x %d k-iters\n", gg->H, gg->W, gg->Cin,
             gg->Cout, gg->R, gg->stride, p.BM, p.BN, p.MTw * p.NTw, p.splits, p.kt_per_split);
   const bool incr = g.Ho * g.Wo > BK && BK / g.Wo + 1 <= g.Ho;
-#define BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, INCR_, NP_, MTAP_)                                                                     \
-  hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, WM_, WN_, INCR_, NP_, MTAP_>), grid, dim3(64 * WM_ * WN_), 0, s, dy, x,      \
+#define BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, INCR_, NP_, MTAP_, KW_)                                                                \
+  hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, WM_, WN_, INCR_, NP_, MTAP_, KW_>), grid, dim3(64 * WM_ * WN_), 0, s, dy, x, \
                      (float*)slab, g, p.MTw, p.NTw, p.kt_per_split)
-#define BDV_WGRAD_PL(BM_, BN_, WM_, WN_, MTAP_)                                                                                  \
+#define BDV_WGRAD_PL(BM_, BN_, WM_, WN_, MTAP_, KW_)                                                                             \
   do {                                                                                                                           \
-    if (incr && pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 3, MTAP_);                                                  \
-    else if (pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 3, MTAP_);                                                    \
-    else if (incr) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 1, MTAP_);                                                            \
-    else BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 1, MTAP_);                                                                     \
+    if (incr && pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 3, MTAP_, KW_);                                             \
+    else if (pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 3, MTAP_, KW_);                                               \
+    else if (incr) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 1, MTAP_, KW_);                                                       \
+    else BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 1, MTAP_, KW_);                                                                \
   } while (0)
-  if (p.form == 1) BDV_WGRAD_PL(64, 192, 2, 2, true);
-  else if (p.form == 2) BDV_WGRAD_PL(64, 64, 2, 2, false);
-  else if (p.form == 3) BDV_WGRAD_PL(256, 64, 4, 1, false);
-  else if (p.form == 4) BDV_WGRAD_PL(64, 256, 1, 4, false);
-  else if (p.form == 5) BDV_WGRAD_PL(64, 256, 1, 4, true);
-  else if (p.BM == 256 && p.BN == 256) BDV_WGRAD_PL(256, 256, 2, 4, false);
-  else if (p.BM == 256) BDV_WGRAD_PL(256, 128, 2, 4, false);
-  else if (p.BN == 256) BDV_WGRAD_PL(128, 256, 2, 4, false);
-  else BDV_WGRAD_PL(128, 128, 2, 4, false);
+  const bool two_stage = wgrad_two_stage();
+  if (p.form == 1) BDV_WGRAD_PL(64, 192, 2, 2, true, 32);
+  else if (p.form == 2) BDV_WGRAD_PL(64, 64, 2, 2, false, 32);
+  else if (p.form == 3) BDV_WGRAD_PL(256, 64, 4, 1, false, 32);
+  else if (p.form == 4) BDV_WGRAD_PL(64, 256, 1, 4, false, 32);
+  else if (p.form == 5) BDV_WGRAD_PL(64, 256, 1, 4, true, 32);
+  else if (p.BM == 256 && p.BN == 256 && two_stage) BDV_WGRAD_PL(256, 256, 2, 4, false, 16);
+  else if (p.BM == 256 && p.BN == 256) BDV_WGRAD_PL(256, 256, 2, 4, false, 32);
+  else if (p.BM == 256 && two_stage) BDV_WGRAD_PL(256, 128, 2, 4, false, 16);
+  else if (p.BM == 256) BDV_WGRAD_PL(256, 128, 2, 4, false, 32);
+  else if (p.BN == 256 && two_stage) BDV_WGRAD_PL(128, 256, 2, 4, false, 16);
+  else if (p.BN == 256) BDV_WGRAD_PL(128, 256, 2, 4, false, 32);
+  else BDV_WGRAD_PL(128, 128, 2, 4, false, 32);
 #undef BDV_WGRAD_PL
 #undef BDV_WGRAD_PL2
   BDV_LAUNCH_CHECK("bdv_conv_wgrad_partial_pl");

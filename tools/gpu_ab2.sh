@@ -1,8 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for i in 1 2 3; do
-timeout -k 10 300 python bench.py --steps 12 --warmup 4 --no-cpu-baseline > gpurun_out/bench_a$i.log 2>&1
-echo "[default $i] rc=$?"; tail -n 1 gpurun_out/bench_a$i.log | cut -c58-110
-BDVCIL_BN_NT=1 timeout -k 10 300 python bench.py --steps 12 --warmup 4 --no-cpu-baseline > gpurun_out/bench_b$i.log 2>&1
-echo "[BN_NT $i] rc=$?"; tail -n 1 gpurun_out/bench_b$i.log | cut -c58-110
-done
+timeout -k 10 600 python -m pytest tests/test_ops_gpu.py tests/test_conv_gpu.py -m gpu -q -x > gpurun_out/pytest_ops.log 2>&1
+echo "[pytest_ops] rc=$?"; tail -n 2 gpurun_out/pytest_ops.log
+timeout -k 10 500 python tools/ab_step.py 4 10 > gpurun_out/ab_step.log 2>&1; tail -5 gpurun_out/ab_step.log
