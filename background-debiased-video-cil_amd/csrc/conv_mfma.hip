@@ -2300,8 +2300,9 @@ __device__ __forceinline__ bf16x8_t pl_frag_tr(const unsigned char* __restrict__
 // WM x WN waves; the 4-wave forms (64-wide tiles, 60-72 KB of LDS) run two workgroups per CU.
 // KW = pixels per LDS stage.  32: one stage, two barriers per step (load -> barrier -> split + store -> barrier -> MFMAs).
 // 16: two stages of 16 pixels in the same LDS and two register sets, pl_pipeline2: the split + store of the next 16 pixels and the
-// loads of the ones after are issued among the MFMAs of the current stage, one barrier per 16 pixels -- for the tiles with at
-// least 24 MFMAs per wave and stage.
+// loads of the ones after are issued among the MFMAs of the current stage, one barrier per 16 pixels -- used for the 128 x 256 and
+// 256 x 128 tiles (0.349 -> 0.315 ms on the 256 -> 128 site, 0.181 -> 0.162 on 128 <-> 512); the 256 x 256 tile has no registers
+// left for a second set.
 template <int BM, int BN, int WM, int WN, bool INCR, int NP = 3, bool MTAP = false, int KW = 32>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                          float* __restrict__ slab, Geom g, int MTw, int NTw,
@@ -2854,6 +2855,8 @@ WgradPlPlan plan_wgrad_pl(const bdv_conv_geom* g) {
   static const int kBM[6] = {0, 64, 64, 256, 64, 64}, kBN[6] = {0, 192, 64, 64, 256, 256};
   p.BM = p.form == 0 ? (g->Cout % 256 == 0 ? 256 : 128) : kBM[p.form];
   p.BN = p.form == 0 ? (g->Cin % 256 == 0 ? 256 : 128) : kBN[p.form];
+  // (256 x 256 one-stage against the two-stage 128 x 256 / 256 x 128 tiles on the sites that allow both: 0.295-0.315 against
+  // 0.308-0.329 ms on the 3x3 sites, 0.153-0.163 against 0.150-0.158 on the 1x1 sites: the larger tile stays)
   p.MTw = g->Cout / p.BM;
   p.NTw = (g->R * g->S * g->Cin + p.BN - 1) / p.BN;
   const int64_t M = (int64_t)g->N * g->Ho * g->Wo;
@@ -3431,8 +3434,7 @@ extern "C" int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const 
   else if (p.form == 3) BDV_WGRAD_PL(256, 64, 4, 1, false, 32);
   else if (p.form == 4) BDV_WGRAD_PL(64, 256, 1, 4, false, 32);
   else if (p.form == 5) BDV_WGRAD_PL(64, 256, 1, 4, true, 32);
-  else if (p.BM == 256 && p.BN == 256 && two_stage) BDV_WGRAD_PL(256, 256, 2, 4, false, 16);
-  else if (p.BM == 256 && p.BN == 256) BDV_WGRAD_PL(256, 256, 2, 4, false, 32);
+  else if (p.BM == 256 && p.BN == 256) BDV_WGRAD_PL(256, 256, 2, 4, false, 32);   // two register sets would spill here (128 accumulators)
   else if (p.BM == 256 && two_stage) BDV_WGRAD_PL(256, 128, 2, 4, false, 16);
   else if (p.BM == 256) BDV_WGRAD_PL(256, 128, 2, 4, false, 32);
   else if (p.BN == 256 && two_stage) BDV_WGRAD_PL(128, 256, 2, 4, false, 16);
