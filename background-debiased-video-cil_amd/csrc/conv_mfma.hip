@@ -391,7 +391,8 @@ __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32]
       }
     }
   }
-  if (do_stat) stat_flush<BN, NT>(sa, stat, smem, g.Cin, mt, nt, tid);
+  // stride 2: one block of stat.MT / 4 partial rows per parity class (blockIdx.y); stride 1: gridDim.y == 1
+  if (do_stat) stat_flush<BN, NT>(sa, stat, smem, g.Cin, blockIdx.y * (stat.MT / gridDim.y) + mt, nt, tid);
 }
 
 // BatchNorm batch statistics fused into the fprop epilogue: per tile, the column sums of y and y^2 over the
@@ -3007,8 +3008,10 @@ extern "C" int bdv_conv_fprop_x3(const float* x, const float* w, float* y, const
 
 extern "C" int bdv_conv_dgrad_stat_rows(const bdv_conv_geom* gg) {
   if (check_geom(gg, "bdv_conv_dgrad_stat_rows")) return 0;
-  const int64_t M = (int64_t)gg->N * gg->H * gg->W;
-  return (int)((M + 127) / 128);
+  const int st = gg->stride;
+  if (st == 1) return (int)(((int64_t)gg->N * gg->H * gg->W + 127) / 128);
+  const int64_t Mc0 = (int64_t)gg->N * ((gg->H + st - 1) / st) * ((gg->W + st - 1) / st);  // largest parity class
+  return (int)(st * st * ((Mc0 + 127) / 128));
 }
 
 namespace {
@@ -3019,7 +3022,8 @@ int conv_dgrad_impl(const float* dy, const float* w, const float* w_t, float* dx
   if (int e = check_geom(gg, "bdv_conv_dgrad")) return e;
   BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   if (bn_stat != nullptr) {
-    BDV_REQUIRE(gg->stride == 1, "bdv_conv_dgrad: fused BatchNorm statistics need stride 1");
+    BDV_REQUIRE(gg->stride == 1 || (gg->R >= gg->stride && gg->S >= gg->stride),
+                "bdv_conv_dgrad: fused BatchNorm statistics with stride 2 need a filter that reaches every input pixel (R, S >= 2)");
     BDV_REQUIRE(bn_stat->y && bn_stat->mean && bn_stat->invstd && bn_stat->partial, "bdv_conv_dgrad: null pointer in bdv_bn_stat_fuse");
     BDV_REQUIRE(bdv_aligned16(bn_stat->y) && bdv_aligned16(bn_stat->mean) && bdv_aligned16(bn_stat->invstd) &&
                     bdv_aligned16(bn_stat->partial), "bdv_conv_dgrad: bdv_bn_stat_fuse pointers must be 16-byte aligned");
@@ -3030,6 +3034,8 @@ int conv_dgrad_impl(const float* dy, const float* w, const float* w_t, float* dx
     stat.invstd = bn_stat->invstd;
     stat.partial = bn_stat->partial;
     stat.MT = bdv_conv_dgrad_stat_rows(gg);
+    if (gg->stride != 1)  // parity classes of odd-sized inputs have fewer row tiles than the largest: their rows stay zero
+      (void)hipMemsetAsync(bn_stat->partial, 0, (size_t)2 * stat.MT * gg->Cin * sizeof(float), (hipStream_t)stream);
   }
   BDV_REQUIRE(dy && w && dx, "bdv_conv_dgrad: null pointer");
   BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(w) && bdv_aligned16(dx) && bdv_aligned16(workspace),
@@ -3153,9 +3159,12 @@ extern "C" int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* gg, int pieces) 
 
 extern "C" int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* gg, int pieces) {
   if (check_geom(gg, "bdv_conv_dgrad_pl_stat_rows")) return 0;
-  if (!pl_dgrad_ok(gg, pieces) || gg->stride != 1) return bdv_conv_dgrad_stat_rows(gg);
-  const PlPlan p = plan_pl(pl_dgrad_cfg(gg, pieces), gg->N * gg->H * gg->W, gg->Cin, gg->R * gg->S * gg->Cout / BK, kMaxSplitWorkspace, true);
-  return p.cfg >= 0 ? p.MT : 0;
+  if (!pl_dgrad_ok(gg, pieces)) return bdv_conv_dgrad_stat_rows(gg);
+  const int st = gg->stride;
+  const int Mc0 = gg->N * ((gg->H + st - 1) / st) * ((gg->W + st - 1) / st);
+  const PlPlan p = plan_pl(pl_dgrad_cfg(gg, pieces), st == 1 ? gg->N * gg->H * gg->W : Mc0, gg->Cin, gg->R * gg->S * gg->Cout / BK,
+                           kMaxSplitWorkspace, st == 1);
+  return p.cfg >= 0 ? st * st * p.MT : 0;
 }
 
 extern "C" int bdv_conv_split_weights(const float* w, const bdv_conv_geom* gg, void* planes_fprop, void* planes_dgrad, void* stream) {
@@ -3240,7 +3249,8 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
                            gg->Cout % BK == 0 && r1_planes_enabled() ? planes_dgrad : nullptr);
   BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   if (bn_stat != nullptr) {
-    BDV_REQUIRE(gg->stride == 1, "bdv_conv_dgrad_pl: fused BatchNorm statistics need stride 1");
+    BDV_REQUIRE(gg->stride == 1 || (gg->R >= gg->stride && gg->S >= gg->stride),
+                "bdv_conv_dgrad_pl: fused BatchNorm statistics with stride 2 need a filter that reaches every input pixel (R, S >= 2)");
     BDV_REQUIRE(bn_stat->y && bn_stat->mean && bn_stat->invstd && bn_stat->partial, "bdv_conv_dgrad_pl: null pointer in bdv_bn_stat_fuse");
     BDV_REQUIRE(bdv_aligned16(bn_stat->y) && bdv_aligned16(bn_stat->mean) && bdv_aligned16(bn_stat->invstd) &&
                     bdv_aligned16(bn_stat->partial), "bdv_conv_dgrad_pl: bdv_bn_stat_fuse pointers must be 16-byte aligned");
@@ -3266,8 +3276,10 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
                      workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, st == 1);
   BDV_REQUIRE(p.cfg >= 0, "bdv_conv_dgrad_pl: no tile configuration for Cin=%d", g.Cin);
   if (st != 1) p.wk.dp_tiles = ((p.MT + 7) / 8) * 8 * p.NT;  // padded grid per parity class
-  // the statistics partial has one row per row tile of THIS kernel
-  stat.MT = p.MT;
+  // the statistics partial has one row per row tile of THIS kernel (stride 2: per parity class and row tile)
+  stat.MT = st * st * p.MT;
+  if (st != 1 && stat.y != nullptr)
+    (void)hipMemsetAsync(stat.partial, 0, (size_t)2 * stat.MT * g.Cin * sizeof(float), s);
   const int work_items = p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split;
   const dim3 grid(work_items, st * st);
   float* slab = (float*)workspace;

@@ -400,8 +400,9 @@ def _block_backward(saved, params, geoms, n_main, has_down, dout, need_params, n
         part = None
         if i > 0:
             gi = geoms[i]
-            if FUSE_BN_STATS and gi.stride == 1:
+            if FUSE_BN_STATS and (gi.stride == 1 or (gi.R > 1 and gi.S > 1 and gi.fold == 0)):
                 # this dgrad produces the gradient entering unit i-1's BN+ReLU: take its statistics in the epilogue
+                # (stride 2: a 3x3 filter reaches every input pixel, one block of partial rows per parity class)
                 d, part = K.conv_dgrad(dy, weight_krsc(wt), gi, bn_stats=(ys[i - 1], masks[i - 1], means[i - 1], invstds[i - 1]))
             else:
                 d = K.conv_dgrad(dy, weight_krsc(wt), gi)

@@ -282,7 +282,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
                ws_tag: str = 'conv', bn_stats=None, x3: Optional[bool] = None):
     """``bn_stats = (y, relu_mask | None, mean, invstd)`` of the conv unit whose output gradient this dgrad produces:
     the BatchNorm-backward statistics are then taken in the epilogue and ``(dx, partial)`` is returned; pass ``partial``
-    to ``bn_backward(stat_partial=...)``.  Needs stride 1 and no temporal shift."""
+    to ``bn_backward(stat_partial=...)``.  Stride 2 needs a filter that reaches every input pixel (R, S >= 2)."""
     _chk_conv(dy, (g.N, g.Ho, g.Wo, g.Cout), g, 'dy')
     _chk(w, (g.Cout, g.R, g.S, g.Cin), name='w')
     dx = out if out is not None else torch.empty((g.N, g.H, g.W, g.Cin), dtype=torch.float32, device=dy.device)

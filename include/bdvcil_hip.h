@@ -90,7 +90,9 @@ int bdv_conv_fprop_x3(const float* x, const float* w, float* y, const bdv_conv_g
 /* BatchNorm-backward statistics fused into dgrad: dx (the gradient w.r.t. the BN(+ReLU) output of the PREVIOUS conv unit,
  * whose saved conv output is y) is reduced in the dgrad epilogue to partial[0][r][c] = sum(g), partial[1][r][c] =
  * sum(g * xhat) per 128-row tile r (g = dx * mask, xhat = (y - mean) * invstd; rows = bdv_conv_dgrad_stat_rows(g));
- * bdv_bn_backward(stat_partial = ...) then skips its own statistics pass.  Needs stride 1. */
+ * bdv_bn_backward(stat_partial = ...) then skips its own statistics pass.  Stride 2 needs a filter that
+ * reaches every input pixel (R, S >= 2); the partial then has one block of rows per input-parity class
+ * (bdv_conv_dgrad_stat_rows / bdv_conv_dgrad_pl_stat_rows give the total) and is zeroed by the call. */
 typedef struct bdv_bn_stat_fuse {
   const float* y;            /* [N,H,W,Cin] conv output of the previous unit */
   const uint32_t* relu_mask; /* 1 bit per element of dx, or NULL (no ReLU) */
