@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # is then the caller's business
 _OVERRIDE = os.environ.get('BDVCIL_LIB_PATH')
 LIB_PATH = _OVERRIDE or os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _lib = None
 
@@ -23,7 +23,7 @@ _lib = None
 class ConvGeom(Structure):
     """Mirror of ``bdv_conv_geom``."""
     _fields_ = [(n, c_int32) for n in
-                ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'R', 'S', 'stride', 'pad', 'T', 'fold', 'pad_w')]
+                ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'R', 'S', 'stride', 'pad', 'T', 'fold', 'pad_w', 'Rt', 'st_t')]
 
     def key(self):
         return tuple(getattr(self, n) for n, _ in self._fields_)

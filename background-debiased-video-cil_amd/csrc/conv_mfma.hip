@@ -27,6 +27,9 @@ constexpr int BK = 32;
 
 struct Geom {
   int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, pad_w, T, fold;  // pad: rows (H), pad_w: columns (W)
+  int Rt, st_t;  // temporal filter taps / temporal stride of the I3D stem (Cin = 4 only; 1, 1 otherwise): output frame n reads the
+                 // input frames n * st_t + dt - Rt / 2 of its clip, dt = 0 .. Rt - 1 (T = OUTPUT frames per clip, T * st_t input frames)
+  float rcp_RS, rcp_S;
   int M;     // GEMM rows: N*Ho*Wo (fprop / wgrad reduction length), N*H*W (dgrad)
   int Ktot;  // fprop: R*S*Cin ; dgrad: R*S*Cout ; wgrad: row length of dw = R*S*Cin
   float rcp_HoWo, rcp_Wo;  // fast division helpers (dividends < 2^22)
@@ -987,11 +990,12 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_c4_x3_kernel(const float* _
   const int wm0 = (wave / WN) * 32, wn0 = (wave % WN) * 32;
   const int arow = tid >> 3, kg = tid & 7;
   const int HoWo = g.Ho * g.Wo;
-  const int RS = g.R * g.S;
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * g.H * g.W * 16, 0x00020000);
+  const int RS = g.R * g.S, RST = RS * g.Rt;
+  const int Tin = g.T * g.st_t, pad_t = g.Rt / 2;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * g.st_t * g.H * g.W * 16, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, g.Cout * g.Ktot * 4, 0x00020000);
 
-  int a_base[AP], a_hi0[AP], a_wi0[AP];
+  int a_base[AP], a_hi0[AP], a_wi0[AP], a_t0[AP];
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
     const int m = mt * BM + arow + 32 * p;
@@ -1002,17 +1006,21 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_c4_x3_kernel(const float* _
     const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
     a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);
     a_wi0[p] = wo * g.stride - g.pad_w;
-    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad_w) * 16;
+    a_t0[p] = (n % g.T) * g.st_t - pad_t;       // input frame (in its clip) that temporal tap 0 reads; T = 1 without temporal taps
+    a_base[p] = (((n * g.st_t - pad_t) * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad_w) * 16;
   }
   float4 ra[AP], rb[BP];
   auto load = [&](int kt) {
-    const int tap = kt * (BK / 4) + kg;  // this thread's filter tap
-    const int r = tap / g.S, s = tap - r * g.S;
-    const bool kv = tap < RS;
+    const int tap = kt * (BK / 4) + kg;  // this thread's filter tap = (dt * R + r) * S + s
+    int dt, rs, r, s;
+    fast_divmod(tap, RS, g.rcp_RS, dt, rs);
+    fast_divmod(rs, g.S, g.rcp_S, r, s);
+    const bool kv = tap < RST;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const bool v = kv && (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W;
-      ra[p] = buf_load16(xr, (a_base[p] + (r * g.W + s) * 16) | (v ? 0 : kOOB), 0);
+      const bool v = kv && (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W &&
+                     (unsigned)(a_t0[p] + dt) < (unsigned)Tin;
+      ra[p] = buf_load16(xr, (a_base[p] + ((dt * g.H + r) * g.W + s) * 16) | (v ? 0 : kOOB), 0);
     }
 #pragma unroll
     for (int p = 0; p < BP; ++p)
@@ -2332,7 +2340,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
   const int wm = wave / WN, wn = wave % WN;
   const int HoWo = g.Ho * g.Wo;
   const int frame_bytes = g.H * g.W * g.Cin * 4;
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * frame_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * g.st_t * frame_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.M * g.Cout * 4, 0x00020000);
 
   // A: dy rows m0 + krow, columns mt*BM + 4*c4
@@ -2350,11 +2358,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
     const int idx = tid + NTHR * p;
     b_krow[p] = idx / BV;
     const int col = nt * BN + 4 * (idx % BV);
-    const int tap = MTAP ? col / g.Cin : (nt * BN) / g.Cin;   // one tap per tile unless MTAP
+    const int tap = MTAP ? col / g.Cin : (nt * BN) / g.Cin;   // one tap per tile unless MTAP; tap = (dt * R + r) * S + s
     const int ci = col - tap * g.Cin;
-    b_r[p] = (!MTAP || tap < g.R * g.S) ? tap / g.S - g.pad : -(1 << 20);   // columns past the last tap (stem: 49 taps in 64) load zeros
-    b_s[p] = tap % g.S - g.pad_w;
-    b_cls[p] = shift_class(ci, g.fold);
+    const int dt = MTAP ? tap / (g.R * g.S) : 0, rs = tap - dt * g.R * g.S;
+    b_r[p] = (!MTAP || tap < g.Rt * g.R * g.S) ? rs / g.S - g.pad : -(1 << 20);   // columns past the last tap (stem: 49 taps in 64) load zeros
+    b_s[p] = rs % g.S - g.pad_w;
+    // frame offset of the tap in input frames: the temporal shift's -1 / 0 / +1, or the stem's temporal tap dt - Rt / 2
+    b_cls[p] = shift_class(ci, g.fold) + (MTAP ? dt - g.Rt / 2 : 0);
     b_off[p] = ((b_r[p] * g.W + b_s[p]) * g.Cin + ci) * 4 + b_cls[p] * frame_bytes;
   }
 
@@ -2370,7 +2380,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
   const int px = g.Cin * 4;
   const int inc0 = (d_ho * st * g.W + d_wo * st) * px;
   const int inc1 = (st * g.W - wrap_w) * px;
-  const int inc2 = (g.H * g.W - wrap_h * g.W) * px;
+  const int inc2 = (g.st_t * g.H * g.W - wrap_h * g.W) * px;   // to the next output frame = st_t input frames on
   int s_hi[BP], s_wi[BP], s_t[BP], s_off[BP];
   if (INCR) {
 #pragma unroll
@@ -2382,7 +2392,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
       s_hi[p] = ho * st;
       s_wi[p] = wo * st;
       s_t[p] = n % g.T;
-      s_off[p] = ((n * g.H + s_hi[p]) * g.W + s_wi[p]) * px + b_off[p];
+      s_off[p] = ((n * g.st_t * g.H + s_hi[p]) * g.W + s_wi[p]) * px + b_off[p];
     }
   }
 
@@ -2422,10 +2432,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
         hi = ho * st;
         wi_ = (rem - ho * g.Wo) * st;
         t = n % g.T;
-        off = ((n * g.H + hi) * g.W + wi_) * px + b_off[p];
+        off = ((n * g.st_t * g.H + hi) * g.W + wi_) * px + b_off[p];
       }
       const bool v = mok && (unsigned)(hi + b_r[p]) < (unsigned)g.H && (unsigned)(wi_ + b_s[p]) < (unsigned)g.W &&
-                     (unsigned)(t + b_cls[p]) < (unsigned)g.T;
+                     (unsigned)(t * g.st_t + b_cls[p]) < (unsigned)(g.T * g.st_t);
       rb[SET][p] = buf_load16(xr, off | (v ? 0 : kOOB), 0);
     }
   };
@@ -2516,6 +2526,11 @@ int check_geom(const bdv_conv_geom* g, const char* who) {
   BDV_REQUIRE(g->Ho == (g->H + 2 * g->pad - g->R) / g->stride + 1 && g->Wo == (g->W + 2 * pad_w - g->S) / g->stride + 1,
               "%s: Ho/Wo inconsistent with H/W/pad/stride", who);
   BDV_REQUIRE(g->Cin % BK == 0 || g->Cin == 4, "%s: Cin=%d must be a multiple of 32 (or exactly 4)", who, g->Cin);
+  if (g->Rt > 1) {
+    BDV_REQUIRE(g->Cin == 4 && g->fold == 0, "%s: temporal taps (Rt=%d) are implemented for the stem only (Cin = 4, no shift)", who, g->Rt);
+    BDV_REQUIRE((g->st_t == 1 || g->st_t == 2) && g->T > 0 && g->N % g->T == 0, "%s: Rt=%d needs st_t 1|2 and N %% T == 0 (T = output frames per clip)", who, g->Rt);
+    BDV_REQUIRE((int64_t)g->N * g->st_t * g->H * g->W * g->Cin < (1ll << 29), "%s: input exceeds 2^29 elements", who);
+  }
   if (g->fold > 0) {
     BDV_REQUIRE(g->fold % 4 == 0 && 2 * g->fold <= g->Cin, "%s: fold=%d must be a multiple of 4 and <= Cin/2", who,
                 g->fold);
@@ -2535,8 +2550,12 @@ Geom make_geom(const bdv_conv_geom* g) {
   Geom d;
   d.N = g->N; d.H = g->H; d.W = g->W; d.Cin = g->Cin; d.Ho = g->Ho; d.Wo = g->Wo; d.Cout = g->Cout;
   d.R = g->R; d.S = g->S; d.stride = g->stride; d.pad = g->pad; d.pad_w = g->pad_w < 0 ? g->pad : g->pad_w;
-  d.T = g->fold > 0 ? g->T : 1;
+  d.T = (g->fold > 0 || g->Rt > 1) ? g->T : 1;
   d.fold = g->fold;
+  d.Rt = g->Rt > 1 ? g->Rt : 1;
+  d.st_t = g->Rt > 1 ? g->st_t : 1;
+  d.rcp_RS = 1.0f / (float)(g->R * g->S);
+  d.rcp_S = 1.0f / (float)g->S;
   d.M = 0; d.Ktot = 0;
   d.rcp_HoWo = 1.0f / (float)(g->Ho * g->Wo);
   d.rcp_Wo = 1.0f / (float)g->Wo;
@@ -2840,7 +2859,7 @@ int pl_wgrad_form(const bdv_conv_geom* g) {
   if (g->Cout == 64 && g->Cin == 64) return RS % 3 == 0 ? 1 : RS == 1 ? 2 : -1;
   if (g->Cout % 256 == 0 && g->Cin == 64 && RS == 1) return 3;
   if (g->Cout == 64 && g->Cin % 256 == 0 && RS == 1) return 4;
-  if (g->Cout == 64 && g->Cin == 4 && RS <= 64 && c4_x3_enabled()) return 5;
+  if (g->Cout == 64 && g->Cin == 4 && c4_x3_enabled()) return 5;   // any number of taps: tiles of 64 taps (Rt * R * S of them)
   return -1;
 }
 bool pl_wgrad_ok(const bdv_conv_geom* g) { return pl_wgrad_form(g) >= 0; }
@@ -2859,7 +2878,7 @@ WgradPlPlan plan_wgrad_pl(const bdv_conv_geom* g) {
   // (256 x 256 one-stage against the two-stage 128 x 256 / 256 x 128 tiles on the sites that allow both: 0.295-0.315 against
   // 0.308-0.329 ms on the 3x3 sites, 0.153-0.163 against 0.150-0.158 on the 1x1 sites: the larger tile stays)
   p.MTw = g->Cout / p.BM;
-  p.NTw = (g->R * g->S * g->Cin + p.BN - 1) / p.BN;
+  p.NTw = ((g->Rt > 1 ? g->Rt : 1) * g->R * g->S * g->Cin + p.BN - 1) / p.BN;
   const int64_t M = (int64_t)g->N * g->Ho * g->Wo;
   const int nkt = (int)((M + BK - 1) / BK);
   const int tiles = p.MTw * p.NTw;
@@ -2868,7 +2887,7 @@ WgradPlPlan plan_wgrad_pl(const bdv_conv_geom* g) {
   // operands from HBM (a K-step reads 32 x (BM + BN) floats; 256 CUs share ~5 TB/s)
   const double t_iter = p.form == 0 ? 2.7 * (double)(p.BM * p.BN) / (128.0 * 256.0)
                                     : fmax(2.7 * (double)(p.BM * p.BN) / (128.0 * 256.0) * 2.0, 32.0 * (p.BM + p.BN) * 4.0 * 2.0 / 20.0e3);
-  const double dw_bytes = (double)g->Cout * g->R * g->S * g->Cin * 4.0;
+  const double dw_bytes = (double)g->Cout * (g->Rt > 1 ? g->Rt : 1) * g->R * g->S * g->Cin * 4.0;
   int best_s = 1;
   double best_cost = 1e30;
   for (int k = 1; k <= 6; ++k) {  // k rounds of 256 blocks
@@ -2902,7 +2921,7 @@ extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
   FdPlan p;
   if (kind == 0) {
     g.M = g.N * g.Ho * g.Wo;
-    g.Ktot = g.R * g.S * g.Cin;
+    g.Ktot = g.Rt * g.R * g.S * g.Cin;
     p = plan_fprop(g, kMaxSplitWorkspace);
   } else {
     if (gg->Cin % 64 != 0) return 0;
@@ -2953,7 +2972,7 @@ int conv_fprop_impl(const float* x, const float* w, float* y, const bdv_conv_geo
               "bdv_conv_fprop: pointers must be 16-byte aligned");
   Geom g = make_geom(gg);
   g.M = g.N * g.Ho * g.Wo;
-  g.Ktot = g.R * g.S * g.Cin;
+  g.Ktot = g.Rt * g.R * g.S * g.Cin;
   hipStream_t s = (hipStream_t)stream;
   const bool c4 = (g.Cin % BK) != 0;
   const FdPlan p = plan_fprop(g, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, x3 && !c4);
@@ -2963,6 +2982,7 @@ int conv_fprop_impl(const float* x, const float* w, float* y, const bdv_conv_geo
   if (debug_plan())
     fprintf(stderr, "[bdv plan] fprop %dx%d Cin %d Cout %d k%d s%d: tiles %d nk %d -> dp %d rem %d split %d\n", g.H, g.W,
             g.Cin, g.Cout, g.R, g.stride, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split);
+  BDV_REQUIRE(gg->Rt <= 1 || (c4 && x3 && c4_x3_enabled()), "bdv_conv_fprop: temporal taps (Rt=%d) need the bf16-piece stem kernel (bdv_conv_fprop_x3)", gg->Rt);
   if (c4 && x3 && c4_x3_enabled()) {
     if (p.wide)
       hipLaunchKernelGGL((conv_fprop_c4_x3_kernel<128, 128, 2, 2>), dim3(blocks), dim3(256), 0, s, x, w, y, g, p.NT, epi);
@@ -3203,7 +3223,7 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
               "bdv_conv_fprop_pl: pointers must be 16-byte aligned");
   Geom g = make_geom(gg);
   g.M = g.N * g.Ho * g.Wo;
-  g.Ktot = g.R * g.S * g.Cin;
+  g.Ktot = g.Rt * g.R * g.S * g.Cin;
   BDV_REQUIRE((int64_t)3 * g.Cout * g.Ktot * 2 < (1ll << 31), "bdv_conv_fprop_pl: weight planes exceed 2^31 bytes");
   hipStream_t s = (hipStream_t)stream;
   const PlPlan p = plan_pl(pl_fprop_cfg(gg, pieces), g.M, g.Cout, g.Ktot / BK, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, true);
@@ -3315,6 +3335,7 @@ namespace {
 // main kernel of a weight gradient: split-K partial products into `slab` (plan_wgrad(gg).splits slices of dw's size)
 int wgrad_partial(const char* who, const float* dy, const float* x, const bdv_conv_geom* gg, void* workspace, size_t workspace_bytes,
                   hipStream_t s, int* splits_out, bool x3 = false) {
+  BDV_REQUIRE(gg == nullptr || gg->Rt <= 1, "%s: temporal taps (Rt=%d) need the bf16-piece plane kernel (bdv_conv_wgrad_partial_pl, BDVCIL_C4_X3)", who, gg->Rt);
   const WgradPlan p = plan_wgrad(gg);
   const size_t need = (size_t)p.splits * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(float);
   if (workspace_bytes < need) {
@@ -3323,7 +3344,7 @@ int wgrad_partial(const char* who, const float* dy, const float* x, const bdv_co
   }
   Geom g = make_geom(gg);
   g.M = g.N * g.Ho * g.Wo;
-  g.Ktot = g.R * g.S * g.Cin;
+  g.Ktot = g.Rt * g.R * g.S * g.Cin;
   float* slab = (float*)workspace;
   const dim3 grid(p.MTw * p.NTw * p.splits);
   if (debug_plan())
@@ -3416,14 +3437,14 @@ extern "C" int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const 
     return wgrad_partial("bdv_conv_wgrad_partial_pl", dy, x, gg, slab, slab_bytes, (hipStream_t)stream, &splits, pieces == 3);
   }
   const WgradPlPlan p = plan_wgrad_pl(gg);
-  const size_t need = (size_t)p.splits * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(float);
+  const size_t need = (size_t)p.splits * gg->Cout * (gg->Rt > 1 ? gg->Rt : 1) * gg->R * gg->S * gg->Cin * sizeof(float);
   if (slab_bytes < need) {
     bdv_set_error("bdv_conv_wgrad_partial_pl: slab %zu < required %zu bytes", slab_bytes, need);
     return BDV_EWORKSPACE;
   }
   Geom g = make_geom(gg);
   g.M = g.N * g.Ho * g.Wo;
-  g.Ktot = g.R * g.S * g.Cin;
+  g.Ktot = g.Rt * g.R * g.S * g.Cin;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(p.MTw * p.NTw * p.splits);
   if (debug_plan())

@@ -62,12 +62,22 @@ def workspace(nbytes: int, device, tag='ws') -> torch.Tensor:
     return cur
 
 
-def make_geom(N, H, W, Cin, Cout, R, S, stride, pad, T=1, fold=0, pad_w=None) -> ConvGeom:
-    """``pad`` pads rows and columns unless ``pad_w`` gives the column padding separately (k x 1 temporal convolutions)."""
+def make_geom(N, H, W, Cin, Cout, R, S, stride, pad, T=1, fold=0, pad_w=None, rt=0, st_t=0) -> ConvGeom:
+    """``pad`` pads rows and columns unless ``pad_w`` gives the column padding separately (k x 1 temporal convolutions).
+    ``rt`` > 1: the I3D stem's temporal taps (Cin = 4): N = output frames, T = output frames per clip, temporal stride ``st_t``;
+    the input then has N * st_t frames and the weight is (Cout, rt * R, S, 4)."""
     pw = pad if pad_w is None else pad_w
     Ho = (H + 2 * pad - R) // stride + 1
     Wo = (W + 2 * pw - S) // stride + 1
-    return ConvGeom(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, T, fold, -1 if pad_w is None else pad_w)
+    return ConvGeom(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, T, fold, -1 if pad_w is None else pad_w, rt, st_t)
+
+
+def _in_frames(g: ConvGeom) -> int:
+    return g.N * g.st_t if g.Rt > 1 else g.N
+
+
+def _taps_r(g: ConvGeom) -> int:
+    return g.R * g.Rt if g.Rt > 1 else g.R
 
 
 def make_temporal_geom(B, T, H, W, Cin, Cout, kt) -> ConvGeom:
@@ -240,8 +250,8 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
     sums (float[2][rows][Cout]) for ``bn_train_finalize``.
     ``affine = (scale, shift, residual | None, relu)``: eval-mode BatchNorm folded into the epilogue,
     y = relu?(conv * scale + shift (+ residual))."""
-    _chk_conv(x, (g.N, g.H, g.W, g.Cin), g, 'x')
-    _chk(w, (g.Cout, g.R, g.S, g.Cin), name='w')
+    _chk_conv(x, (_in_frames(g), g.H, g.W, g.Cin), g, 'x')
+    _chk(w, (g.Cout, _taps_r(g), g.S, g.Cin), name='w')
     y = out if out is not None else torch.empty((g.N, g.Ho, g.Wo, g.Cout), dtype=torch.float32, device=x.device)
     _chk_conv(y, (g.N, g.Ho, g.Wo, g.Cout), g, 'y')
     ws = _conv_ws(g, 0, x.device, ws_tag)
@@ -331,11 +341,11 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, dw: Optional[torc
                beta: float = 0.0, ws_tag: str = 'wgrad', x3: Optional[bool] = None) -> torch.Tensor:
     """dw = beta * dw + dy^T (*) x in one call (split-K main kernel + fixed-order reduction)."""
     _chk_conv(dy, (g.N, g.Ho, g.Wo, g.Cout), g, 'dy')
-    _chk_conv(x, (g.N, g.H, g.W, g.Cin), g, 'x')
+    _chk_conv(x, (_in_frames(g), g.H, g.W, g.Cin), g, 'x')
     if dw is None:
-        dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
+        dw = torch.empty((g.Cout, _taps_r(g), g.S, g.Cin), dtype=torch.float32, device=dy.device)
         beta = 0.0
-    _chk(dw, (g.Cout, g.R, g.S, g.Cin), name='dw')
+    _chk(dw, (g.Cout, _taps_r(g), g.S, g.Cin), name='dw')
     if WGRAD_X3 if x3 is None else x3:      # the bf16-piece main kernel only exists in the partial + reduce form
         slab, _ = conv_wgrad_partial(dy, x, g, x3=True, dw=dw)
         wgrad_reduce_batched([(slab, dw)], beta=beta)
@@ -639,20 +649,20 @@ def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, x3: Optio
     """Split-K partial products of a weight gradient -> (slab (splits, Cout, R, S, Cin), empty dw); reduce them later with
     ``wgrad_reduce_batched`` (the slab must stay alive until then)."""
     _chk_conv(dy, (g.N, g.Ho, g.Wo, g.Cout), g, 'dy')
-    _chk_conv(x, (g.N, g.H, g.W, g.Cin), g, 'x')
+    _chk_conv(x, (_in_frames(g), g.H, g.W, g.Cin), g, 'x')
     use_x3 = WGRAD_X3 if x3 is None else x3
     use_pl = use_x3 and USE_PL_WGRAD
     splits = (lib().bdv_conv_wgrad_pl_splits if use_pl else lib().bdv_conv_wgrad_splits)(ctypes.byref(g))
     if splits <= 0:
         check(-1, 'bdv_conv_wgrad_splits')
-    slab = torch.empty((splits, g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
+    slab = torch.empty((splits, g.Cout, _taps_r(g), g.S, g.Cin), dtype=torch.float32, device=dy.device)
     fn = lib().bdv_conv_wgrad_partial_pl if use_pl else lib().bdv_conv_wgrad_partial_x3 if use_x3 else lib().bdv_conv_wgrad_partial
     if use_pl:
         check(fn(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, PIECES, _stream()), 'bdv_conv_wgrad_partial_pl')
     else:
         check(fn(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, _stream()), 'bdv_conv_wgrad_partial')
     if dw is None:
-        dw = torch.empty((g.Cout, g.R, g.S, g.Cin), dtype=torch.float32, device=dy.device)
+        dw = torch.empty((g.Cout, _taps_r(g), g.S, g.Cin), dtype=torch.float32, device=dy.device)
     return slab, dw
 
 

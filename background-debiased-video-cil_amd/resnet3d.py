@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import List
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -90,26 +92,39 @@ class _Stem3dFn(torch.autograd.Function):
         B = N // T
         Cout, _, kt, kh, kw = weight.shape
         To = (T + 2 * (kt // 2) - kt) // 2 + 1
-        g = K.make_geom(B * To, H, W, 4, Cout, kh, kw, 2, kh // 2)
-        # per temporal tap dt: the frames 2t + dt - 2 of every clip (zero frames outside the clip), and the tap's 7x7 filter
-        xv = x4.view(B, T, H, W, 4)
-        w5 = weight.detach().permute(2, 0, 3, 4, 1)                  # (kt, Cout, kh, kw, 3)
-        taps, ws = [], []
-        for dt in range(kt):
-            idx = [2 * t + dt - kt // 2 for t in range(To)]
-            sel = torch.zeros((B, To, H, W, 4), dtype=torch.float32, device=x4.device)
-            ok = [k for k, i in enumerate(idx) if 0 <= i < T]
-            if ok:
-                sel[:, ok[0]:ok[-1] + 1] = xv[:, idx[ok[0]]:idx[ok[-1]] + 1:2]
-            taps.append(sel.view(B * To, H, W, 4))
-            w4 = torch.zeros((Cout, kh, kw, 4), dtype=torch.float32, device=x4.device)
-            w4[..., :3] = w5[dt]
-            ws.append(w4)
-        one = torch.ones(Cout, dtype=torch.float32, device=x4.device)
-        zero = torch.zeros(Cout, dtype=torch.float32, device=x4.device)
-        y = K.conv_fprop(taps[0], ws[0], g)
-        for dt in range(1, kt):                                       # y += conv(tap dt): residual input of the folded epilogue
-            y = K.conv_fprop(taps[dt], ws[dt], g, affine=(one, zero, y, False))
+        # One kernel over all kt x kh x kw taps (the stem kernels of the bf16-piece arithmetic take temporal taps: output frame n
+        # reads the input frames 2 n + dt - kt // 2 of its clip) when the clip length fits (T = 2 To); otherwise kt accumulated 2-D
+        # convolutions over gathered frames.
+        fused = (T == 2 * To and K.FPROP_X3 and K.WGRAD_X3 and K.USE_PL_WGRAD and os.environ.get('BDVCIL_C4_X3', '1') != '0'
+                 and os.environ.get('BDVCIL_STEM3D_FUSED', '1') != '0')
+        taps = []
+        if fused:
+            g = K.make_geom(B * To, H, W, 4, Cout, kh, kw, 2, kh // 2, T=To, rt=kt, st_t=2)
+            w4 = torch.zeros((Cout, kt, kh, kw, 4), dtype=torch.float32, device=x4.device)
+            w4[..., :3] = weight.detach().permute(0, 2, 3, 4, 1)         # (Cout, kt, kh, kw, 3)
+            y = K.conv_fprop(x4, w4.view(Cout, kt * kh, kw, 4), g)
+            taps = [x4]
+        else:
+            g = K.make_geom(B * To, H, W, 4, Cout, kh, kw, 2, kh // 2)
+            # per temporal tap dt: the frames 2t + dt - 2 of every clip (zero frames outside the clip), and the tap's 7x7 filter
+            xv = x4.view(B, T, H, W, 4)
+            w5 = weight.detach().permute(2, 0, 3, 4, 1)                  # (kt, Cout, kh, kw, 3)
+            ws = []
+            for dt in range(kt):
+                idx = [2 * t + dt - kt // 2 for t in range(To)]
+                sel = torch.zeros((B, To, H, W, 4), dtype=torch.float32, device=x4.device)
+                ok = [k for k, i in enumerate(idx) if 0 <= i < T]
+                if ok:
+                    sel[:, ok[0]:ok[-1] + 1] = xv[:, idx[ok[0]]:idx[ok[-1]] + 1:2]
+                taps.append(sel.view(B * To, H, W, 4))
+                w4 = torch.zeros((Cout, kh, kw, 4), dtype=torch.float32, device=x4.device)
+                w4[..., :3] = w5[dt]
+                ws.append(w4)
+            one = torch.ones(Cout, dtype=torch.float32, device=x4.device)
+            zero = torch.zeros(Cout, dtype=torch.float32, device=x4.device)
+            y = K.conv_fprop(taps[0], ws[0], g)
+            for dt in range(1, kt):                                       # y += conv(tap dt): residual input of the folded epilogue
+                y = K.conv_fprop(taps[dt], ws[dt], g, affine=(one, zero, y, False))
         save = training and any(ctx.needs_input_grad)
         if training:
             rm = bn.running_mean if bn.track_running_stats else None
@@ -126,7 +141,7 @@ class _Stem3dFn(torch.autograd.Function):
         Tp = (To - 1) // 2 + 1
         even = a.view(B, To, g.Ho, g.Wo, Cout)[:, ::2].contiguous().view(B * Tp, g.Ho, g.Wo, Cout)
         p, pidx = K.maxpool_fwd(even)
-        ctx.meta = (g, B, To, Tp, kt)
+        ctx.meta = (g, B, To, Tp, kt, fused)
         ctx.bn_training = training
         if save:
             ctx.save_for_backward(gamma, y, mask, pidx, mean, invstd, *taps)
@@ -137,7 +152,7 @@ class _Stem3dFn(torch.autograd.Function):
         if not ctx.bn_training:
             raise NotImplementedError('backward through eval-mode BatchNorm is not implemented')
         gamma, y, mask, pidx, mean, invstd, *taps = ctx.saved_tensors
-        g, B, To, Tp, kt = ctx.meta
+        g, B, To, Tp, kt, fused = ctx.meta
         Cout = y.shape[-1]
         dp = dp if dp.is_contiguous() else dp.contiguous()
         d_even = K.maxpool_bwd(dp, pidx, (B * Tp, g.Ho, g.Wo, Cout))
@@ -146,8 +161,12 @@ class _Stem3dFn(torch.autograd.Function):
         dy, dgamma, dbeta = K.bn_backward(da.view(B * To, g.Ho, g.Wo, Cout), mask, y, gamma, mean, invstd, True)
         dw = None
         if ctx.needs_input_grad[1]:
-            parts = [K.conv_wgrad(dy, taps[dt], g)[..., :3] for dt in range(kt)]     # each (Cout, kh, kw, 3)
-            dw = torch.stack(parts, dim=1).permute(0, 4, 1, 2, 3)                    # (Cout, 3, kt, kh, kw)
+            if fused:
+                dw4 = K.conv_wgrad(dy, taps[0], g)                                   # (Cout, kt * kh, kw, 4)
+                dw = dw4.view(Cout, kt, g.R, g.S, 4)[..., :3].permute(0, 4, 1, 2, 3)   # (Cout, 3, kt, kh, kw)
+            else:
+                parts = [K.conv_wgrad(dy, taps[dt], g)[..., :3] for dt in range(kt)]     # each (Cout, kh, kw, 3)
+                dw = torch.stack(parts, dim=1).permute(0, 4, 1, 2, 3)                    # (Cout, 3, kt, kh, kw)
         Fn.join_side_stream(dp.device)
         return None, dw, dgamma, dbeta, None, None, None
 

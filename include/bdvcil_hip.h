@@ -47,6 +47,12 @@ typedef struct bdv_conv_geom {
                    * A k x 1 x 1 temporal convolution of an I3D block (UPSTREAM mmaction ResNet3d Bottleneck3d.conv1,
                    * configs/_base_/models/i3d_r50.py:13) runs as a k x 1 conv on the [B][T][H*W][C] view of the same NHWC
                    * storage: N = B, H = T, W = H*W, R = k, S = 1, pad = k / 2, pad_w = 0. */
+  int32_t Rt;     /* temporal filter taps of the I3D stem (UPSTREAM ResNet3d.conv1, conv1_kernel = (5, 7, 7),
+                   * configs/_base_/models/i3d_r50.py:7); 0 or 1 = a 2-D convolution.  Rt > 1: Cin = 4 only, the bf16-piece
+                   * kernels only (bdv_conv_fprop_x3, bdv_conv_wgrad_partial_pl).  N = OUTPUT frames, T = output frames per
+                   * clip; the input holds N * st_t frames and output frame n reads the input frames n * st_t + dt - Rt / 2 of
+                   * its clip (zeros outside).  Weights [Cout][Rt][R][S][4]. */
+  int32_t st_t;   /* temporal stride (1 or 2) when Rt > 1 */
 } bdv_conv_geom;
 
 const char* bdv_last_error(void);

@@ -71,6 +71,36 @@ def test_maxpool_t2(dev):
         K.maxpool_t2_fwd(torch.zeros(3, 6, 6, 64, device=dev))
 
 
+@pytest.mark.parametrize('B,T,H,W,kt', [(2, 8, 20, 24, 5), (1, 4, 18, 22, 5), (3, 6, 16, 16, 3)])
+def test_stem_with_temporal_taps(B, T, H, W, kt, dev):
+    """The stem kernels of the bf16-piece arithmetic with temporal taps (bdv_conv_geom.Rt / st_t): ONE launch for the kt x 7 x 7
+    filter with strides (2, 2, 2), forward and weight gradient, against torch's CPU Conv3d."""
+    from bdvcil_amd import kernels as K
+    gen = torch.Generator().manual_seed(B * 100 + T)
+    Cout, To = 64, T // 2
+    x = torch.randn(B, 3, T, H, W, generator=gen)
+    w = (torch.randn(Cout, 3, kt, 7, 7, generator=gen) / (3 * kt * 49) ** 0.5).requires_grad_(True)
+    y = F.conv3d(x, w, stride=(2, 2, 2), padding=(kt // 2, 3, 3))
+    assert y.shape[2] == To
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    x4 = torch.zeros(B * T, H, W, 4)
+    x4[..., :3] = x.permute(0, 2, 3, 4, 1).reshape(B * T, H, W, 3)
+    w4 = torch.zeros(Cout, kt, 7, 7, 4)
+    w4[..., :3] = w.detach().permute(0, 2, 3, 4, 1)
+    g = K.make_geom(B * To, H, W, 4, Cout, 7, 7, 2, 3, T=To, rt=kt, st_t=2)
+    yd = K.conv_fprop(x4.to(dev), w4.view(Cout, kt * 7, 7, 4).to(dev), g)
+    ref = y.detach().permute(0, 2, 3, 4, 1).reshape(B * To, g.Ho, g.Wo, Cout)
+    assert (yd.cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    dyd = dy.permute(0, 2, 3, 4, 1).reshape(B * To, g.Ho, g.Wo, Cout).contiguous().to(dev)
+    dw = K.conv_wgrad(dyd, x4.to(dev), g).cpu().view(Cout, kt, 7, 7, 4)
+    dref = w.grad.permute(0, 2, 3, 4, 1)
+    assert (dw[..., :3] - dref).abs().max().item() <= 2e-5 * dref.abs().max().item()
+    assert dw[..., 3].abs().max().item() == 0           # the 4th input channel is zero
+    with pytest.raises(Exception):                      # only the bf16-piece stem kernels take temporal taps
+        K.conv_fprop(x4.to(dev), w4.view(Cout, kt * 7, 7, 4).to(dev), g, x3=False)
+
+
 def _cfg(K_):
     return dict(type='Recognizer3D',
                 backbone=dict(type='ResNet3d', pretrained2d=True, pretrained=None, depth=50, conv1_kernel=(5, 7, 7),
