@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # is then the caller's business
 _OVERRIDE = os.environ.get('BDVCIL_LIB_PATH')
 LIB_PATH = _OVERRIDE or os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _lib = None
 
@@ -40,7 +40,8 @@ class ConvAffine(Structure):
 
 class BnStatFuse(Structure):
     """Mirror of ``bdv_bn_stat_fuse``."""
-    _fields_ = [('y', c_void_p), ('relu_mask', c_void_p), ('mean', c_void_p), ('invstd', c_void_p), ('partial', c_void_p)]
+    _fields_ = [('y', c_void_p), ('relu_mask', c_void_p), ('mean', c_void_p), ('invstd', c_void_p), ('partial', c_void_p),
+                ('relu_scale', c_void_p), ('relu_shift', c_void_p)]
 
 
 
@@ -58,26 +59,29 @@ SIGNATURES = {
     'bdv_conv_dgrad_x3': (c_int, [P, P, P, P, P, P, POINTER(ConvGeom), POINTER(BnStatFuse), P, c_size_t, P]),
     'bdv_conv_weight_planes_bytes': (c_size_t, [POINTER(ConvGeom)]),
     'bdv_conv_split_weights': (c_int, [P, POINTER(ConvGeom), P, P, P]),
+    'bdv_conv_fprop_pre_ok': (c_int, [POINTER(ConvGeom)]),
+    'bdv_conv_fprop_pre_stat_rows': (c_int, [POINTER(ConvGeom)]),
+    'bdv_conv_wgrad_pre_ok': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_debug_force_tile': (c_int, [c_int]),
     'bdv_conv_uses_planes': (c_int, [POINTER(ConvGeom), c_int, c_int]),
     'bdv_conv_kernel_name': (c_int, [POINTER(ConvGeom), c_int, c_int, c_char_p, c_size_t]),
     'bdv_conv_fprop_pl_stat_rows': (c_int, [POINTER(ConvGeom), c_int]),
     'bdv_conv_dgrad_pl_stat_rows': (c_int, [POINTER(ConvGeom), c_int]),
-    'bdv_conv_fprop_pl': (c_int, [P, P, P, P, POINTER(ConvGeom), P, POINTER(ConvAffine), P, c_size_t, c_int, P]),
+    'bdv_conv_fprop_pl': (c_int, [P, P, P, P, POINTER(ConvGeom), P, POINTER(ConvAffine), P, c_size_t, c_int, P, P, P]),
     'bdv_conv_dgrad_pl': (c_int, [P, P, P, P, P, P, POINTER(ConvGeom), POINTER(BnStatFuse), P, c_size_t, c_int, P]),
     'bdv_conv_wgrad': (c_int, [P, P, P, c_float, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_conv_wgrad_splits': (c_int, [POINTER(ConvGeom)]),
     'bdv_conv_wgrad_partial': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_conv_wgrad_partial_x3': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, P]),
     'bdv_conv_wgrad_pl_splits': (c_int, [POINTER(ConvGeom)]),
-    'bdv_conv_wgrad_partial_pl': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, c_int, P]),
+    'bdv_conv_wgrad_partial_pl': (c_int, [P, P, POINTER(ConvGeom), P, c_size_t, c_int, P, P, P]),
     'bdv_wgrad_reduce_batched': (c_int, [P, P, P, P, c_int, c_float, P]),
     'bdv_bn_workspace_bytes': (c_size_t, [c_int64, c_int]),
     'bdv_bn_train_stats': (c_int, [P, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_size_t, P]),
     'bdv_bn_train_finalize': (c_int, [P, c_int, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P]),
     'bdv_bn_eval_params': (c_int, [c_int, P, P, P, P, c_float, P, P, P]),
     'bdv_bn_apply': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, P]),
-    'bdv_bn_backward': (c_int, [P, P, P, P, P, P, P, P, P, c_float, c_int64, c_int, c_int, P, c_int, P, c_size_t, P]),
+    'bdv_bn_backward': (c_int, [P, P, P, P, P, P, P, P, P, c_float, c_int64, c_int, c_int, P, c_int, P, P, P, c_size_t, P]),
     'bdv_bn_backward_maxpool': (c_int, [P, P, P, P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'bdv_relu_bwd': (c_int, [P, P, P, P, c_int64, P]),
     'bdv_add': (c_int, [P, P, P, c_int64, P]),

@@ -190,6 +190,11 @@ __device__ __forceinline__ unsigned nibble_gt0(const float4& o) {
 __device__ __forceinline__ unsigned mask_nibble(const uint32_t* __restrict__ mask, int64_t i4) {
   return (mask[i4 >> 3] >> (4 * (int)(i4 & 7))) & 0xFu;
 }
+// ReLU sign bits of 4 channels derived from the conv output: the forward's own expression (bn_apply_kernel / the PRE loaders)
+__device__ __forceinline__ unsigned derive_nibble(const float4 v, const float4 sc, const float4 sh) {
+  return (fmaf(v.x, sc.x, sh.x) > 0.f ? 1u : 0u) | (fmaf(v.y, sc.y, sh.y) > 0.f ? 2u : 0u) | (fmaf(v.z, sc.z, sh.z) > 0.f ? 4u : 0u) |
+         (fmaf(v.w, sc.w, sh.w) > 0.f ? 8u : 0u);
+}
 __device__ __forceinline__ float4 apply_nibble(float4 g, unsigned nib) {
   g.x = (nib & 1u) ? g.x : 0.f;
   g.y = (nib & 2u) ? g.y : 0.f;
@@ -211,10 +216,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
     const int c4 = (int)(i % CV);
     const float4 v = ld4<NT>(y + i), sc = scale[c4], sh = shift[c4];
     float4 o;
-    o.x = v.x * sc.x + sh.x;
-    o.y = v.y * sc.y + sh.y;
-    o.z = v.z * sc.z + sh.z;
-    o.w = v.w * sc.w + sh.w;
+    o.x = fmaf(v.x, sc.x, sh.x);   // explicit: the conv loaders that apply this BatchNorm themselves (PRE) use the same expression
+    o.y = fmaf(v.y, sc.y, sh.y);
+    o.z = fmaf(v.z, sc.z, sh.z);
+    o.w = fmaf(v.w, sc.w, sh.w);
     if (RES) {
       float4 r = ld4<NTR>(res + i);
       if (res_scale != nullptr) {
@@ -238,12 +243,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
 }
 
 // ---- backward ----------------------------------------------------------------------------
-template <bool RELU>
+// RELU: 0 = none, 1 = the forward's 1-bit mask, 2 = the sign derived from y (rscale / rshift: the unit's mask was never written)
+template <int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dout, const uint32_t* __restrict__ mask,
                                                               const float* __restrict__ y, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* __restrict__ p1,
                                                               float* __restrict__ p2, int64_t M, int C, int CVB, int RL,
-                                                              int rows_per_block) {
+                                                              int rows_per_block, const float* __restrict__ rscale,
+                                                              const float* __restrict__ rshift) {
   __shared__ float4 sh[2][256];
   const int tid = threadIdx.x;
   const int cv = tid % CVB, rl = tid / CVB;
@@ -258,8 +265,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   for (int64_t r = r0 + rl; r < r1; r += RL) {
     const int64_t i = r * CV + c4;
     float4 g = reinterpret_cast<const float4*>(dout)[i];
-    if (RELU) g = apply_nibble(g, mask_nibble(mask, i));
     const float4 v = reinterpret_cast<const float4*>(y)[i];
+    if (RELU == 1) g = apply_nibble(g, mask_nibble(mask, i));
+    if (RELU == 2) g = apply_nibble(g, derive_nibble(v, reinterpret_cast<const float4*>(rscale)[c4], reinterpret_cast<const float4*>(rshift)[c4]));
     s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
     s2.x += g.x * ((v.x - mu.x) * is.x);
     s2.y += g.y * ((v.y - mu.y) * is.y);
@@ -298,17 +306,19 @@ __global__ __launch_bounds__(4 * FIN_LANES) void bn_bwd_finalize_kernel(const fl
   coef[2 * C + c] = (float)(s2 / (double)M);
 }
 
-template <bool RELU, bool NT = false>
+template <int RELU, bool NT = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restrict__ dout, const uint32_t* __restrict__ mask,
                                                             const float4* __restrict__ y, const float4* __restrict__ mean,
                                                             const float4* __restrict__ invstd, const float4* __restrict__ coef,
-                                                            float4* __restrict__ dy, int64_t n4, int CV) {
+                                                            float4* __restrict__ dy, int64_t n4, int CV,
+                                                            const float4* __restrict__ rscale, const float4* __restrict__ rshift) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const int c4 = (int)(i % CV);
     float4 g = ld4<NT>(dout + i);
-    if (RELU) g = apply_nibble(g, mask_nibble(mask, i));
     const float4 v = ld4<NT>(y + i), mu = mean[c4], is = invstd[c4];
+    if (RELU == 1) g = apply_nibble(g, mask_nibble(mask, i));
+    if (RELU == 2) g = apply_nibble(g, derive_nibble(v, rscale[c4], rshift[c4]));
     const float4 a = coef[c4], b = coef[CV + c4], c = coef[2 * CV + c4];
     float4 d;
     d.x = a.x * (g.x - b.x - ((v.x - mu.x) * is.x) * c.x);
@@ -505,10 +515,13 @@ extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shi
 extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, const float* y, const float* gamma,
                                const float* save_mean, const float* save_invstd, float* dy, float* dgamma,
                                float* dbeta, float beta_acc, int64_t M, int C, int relu, const float* stat_partial,
-                               int stat_rows, void* workspace, size_t workspace_bytes, void* stream) {
+                               int stat_rows, const float* relu_scale, const float* relu_shift, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   BDV_REQUIRE(dout && y && gamma && save_mean && save_invstd && dy && workspace, "bdv_bn_backward: null pointer");
   BDV_REQUIRE(stat_partial == nullptr || (stat_rows > 0 && bdv_aligned16(stat_partial)), "bdv_bn_backward: bad stat_partial");
-  BDV_REQUIRE(!relu || (relu_mask && C % 32 == 0), "bdv_bn_backward: relu needs the forward ReLU mask (C %% 32 == 0)");
+  const bool derive = relu && relu_mask == nullptr && relu_scale != nullptr;
+  BDV_REQUIRE(!relu || derive || (relu_mask && C % 32 == 0), "bdv_bn_backward: relu needs the forward ReLU mask (C %% 32 == 0) or relu_scale / relu_shift");
+  BDV_REQUIRE(!derive || (relu_shift != nullptr && bdv_aligned16(relu_scale) && bdv_aligned16(relu_shift)), "bdv_bn_backward: relu_scale / relu_shift");
   BDV_REQUIRE(M > 0 && bn_c_ok(C), "bdv_bn_backward: unsupported M=%lld C=%d", (long long)M, C);
   BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(y) && bdv_aligned16(dy) && bdv_aligned16(workspace) &&
                   bdv_aligned16(save_mean) && bdv_aligned16(save_invstd), "bdv_bn_backward: alignment");
@@ -528,12 +541,15 @@ extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, con
     q2 = stat_partial + (size_t)stat_rows * C;
     rows = stat_rows;
   } else {
-    if (relu)
-      hipLaunchKernelGGL((bn_bwd_partial_kernel<true>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean,
-                         save_invstd, p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
+    if (derive)
+      hipLaunchKernelGGL((bn_bwd_partial_kernel<2>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean,
+                         save_invstd, p1, p2, M, C, b.CVB, b.RL, b.rows_per_block, relu_scale, relu_shift);
+    else if (relu)
+      hipLaunchKernelGGL((bn_bwd_partial_kernel<1>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean,
+                         save_invstd, p1, p2, M, C, b.CVB, b.RL, b.rows_per_block, relu_scale, relu_shift);
     else
-      hipLaunchKernelGGL((bn_bwd_partial_kernel<false>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean,
-                         save_invstd, p1, p2, M, C, b.CVB, b.RL, b.rows_per_block);
+      hipLaunchKernelGGL((bn_bwd_partial_kernel<0>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean,
+                         save_invstd, p1, p2, M, C, b.CVB, b.RL, b.rows_per_block, relu_scale, relu_shift);
     BDV_LAUNCH_CHECK("bdv_bn_backward(partial)");
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(4 * FIN_LANES), 0, s, q1, q2, rows, M, C, gamma, save_invstd, dgamma,
@@ -541,15 +557,15 @@ extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, con
   BDV_LAUNCH_CHECK("bdv_bn_backward(finalize)");
   const int64_t n4 = M * C / 4;
   const dim3 grid(ew_grid(n4)), blk(256);
-  if (relu && bn_nt_enabled())
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, blk, 0, s, (const float4*)dout, relu_mask, (const float4*)y,
-                       (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy, n4, C / 4);
-  else if (relu)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), grid, blk, 0, s, (const float4*)dout, relu_mask, (const float4*)y,
-                       (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy, n4, C / 4);
-  else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), grid, blk, 0, s, (const float4*)dout, relu_mask, (const float4*)y,
-                       (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy, n4, C / 4);
+  const float4 *rs4 = (const float4*)relu_scale, *rh4 = (const float4*)relu_shift;
+#define BDV_BWD_APPLY(RELU_, NT_)                                                                                              \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<RELU_, NT_>), grid, blk, 0, s, (const float4*)dout, relu_mask, (const float4*)y,     \
+                     (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy, n4, C / 4, rs4, rh4)
+  const bool nt = bn_nt_enabled();
+  if (derive) { if (nt) BDV_BWD_APPLY(2, true); else BDV_BWD_APPLY(2, false); }
+  else if (relu) { if (nt) BDV_BWD_APPLY(1, true); else BDV_BWD_APPLY(1, false); }
+  else BDV_BWD_APPLY(0, false);
+#undef BDV_BWD_APPLY
   BDV_LAUNCH_CHECK("bdv_bn_backward(apply)");
   return BDV_OK;
 }

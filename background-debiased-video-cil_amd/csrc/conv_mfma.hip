@@ -218,11 +218,13 @@ __device__ __forceinline__ void fprop_store(float* __restrict__ y, const Geom& g
 // order and written to partial[0 | 1][mt][Cin]; the separate statistics pass over dx, y and the mask disappears.
 struct BnStat {
   const float* y;
-  const uint32_t* mask;  // may be null (no ReLU)
+  const uint32_t* mask;  // may be null (no ReLU, or the sign is derived from y: rscale)
   const float* mean;
   const float* invstd;
   float* partial;
   int MT;
+  const float* rscale;   // optional: ReLU sign = y * rscale + rshift > 0 (units whose mask was never written)
+  const float* rshift;
 };
 
 struct StatAcc {
@@ -231,6 +233,13 @@ struct StatAcc {
     s1 = s2 = make_float4(0.f, 0.f, 0.f, 0.f);
     mu = *reinterpret_cast<const float4*>(st.mean + col);
     is = *reinterpret_cast<const float4*>(st.invstd + col);
+  }
+  // ReLU sign bits of 4 channels from the conv output itself (the forward's fused multiply-add); scale / shift are fetched where
+  // they are used (L1-resident) rather than held in 8 more registers through the epilogue
+  __device__ __forceinline__ static unsigned sign_bits(const BnStat& st, int col, const float4 yv) {
+    const float4 rsc = *reinterpret_cast<const float4*>(st.rscale + col), rsh = *reinterpret_cast<const float4*>(st.rshift + col);
+    return (fmaf(yv.x, rsc.x, rsh.x) > 0.f ? 1u : 0u) | (fmaf(yv.y, rsc.y, rsh.y) > 0.f ? 2u : 0u) |
+           (fmaf(yv.z, rsc.z, rsh.z) > 0.f ? 4u : 0u) | (fmaf(yv.w, rsc.w, rsh.w) > 0.f ? 8u : 0u);
   }
   __device__ __forceinline__ void accumulate(const float4 v, const float4 yv) {  // v: masked gradient, yv: conv output
     s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
@@ -302,7 +311,9 @@ __device__ __forceinline__ void staged_epilogue(const f32x16 (&acc)[BM / WM / 32
 // HBM roofline.
 // rowmap(mrow) -> dx pixel index of tile row mrow (identity for stride 1; parity-class map for stride 2).
 
-template <int BM, int BN, int WM, int WN, class RowMap>
+// DERIVE: the ReLU sign of the statistics may come from the conv output itself (BnStat::rscale); compiled out of the fp32-MFMA
+// kernels, whose 168-register budget has no room for it (the model only derives signs in the bf16-piece arithmetic).
+template <int BM, int BN, int WM, int WN, bool DERIVE = true, class RowMap>
 __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ smem, int tid,
                                                float* __restrict__ dx, const float* __restrict__ add_src,
                                                const uint32_t* __restrict__ add_mask, const Geom& g, int mt, int nt, int Mrows,
@@ -383,7 +394,7 @@ __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32]
         r.w += (nib & 8u) ? a[u].w : 0.f;
         buf_store16(dxr, off[u], r);
         if (do_stat && off[u] != kOOB) {
-          const unsigned sn = (sm[u] >> sh) & 0xFu;
+          const unsigned sn = (DERIVE && stat.rscale != nullptr) ? StatAcc::sign_bits(stat, col, yv[u]) : (sm[u] >> sh) & 0xFu;
           float4 gq;
           gq.x = (sn & 1u) ? r.x : 0.f;
           gq.y = (sn & 2u) ? r.y : 0.f;
@@ -395,7 +406,7 @@ __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32]
     }
   }
   // stride 2: one block of stat.MT / 4 partial rows per parity class (blockIdx.y); stride 1: gridDim.y == 1
-  if (do_stat) stat_flush<BN, NT>(sa, stat, smem, g.Cin, blockIdx.y * (stat.MT / gridDim.y) + mt, nt, tid);
+  if (do_stat) stat_flush<BN, NT>(sa, stat, smem, g.Cin, blockIdx.y * (stat.MT >> (gridDim.y == 4 ? 2 : 0)) + mt, nt, tid);
 }
 
 // BatchNorm batch statistics fused into the fprop epilogue: per tile, the column sums of y and y^2 over the
@@ -443,6 +454,10 @@ struct FpropEpi {
   const float* shift;
   const float* res;    // optional residual, same shape as y
   int relu;
+  // BatchNorm + ReLU of the PRODUCER applied to the activation operand in the loader (conv_fprop_pl_kernel<..., PRE>):
+  // a = max(x * pre_scale[ci] + pre_shift[ci], 0)
+  const float* pre_scale;
+  const float* pre_shift;
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -1204,7 +1219,7 @@ __global__ __launch_bounds__(256, 3) void conv_dgrad_kernel(const float* __restr
   // frame n + cls when that frame is inside the clip.  Rows whose target falls outside the clip
   // ("orphans") instead write the zero that the unreachable frame at the other clip end needs,
   // which makes the scatter a bijection over dx.
-  dgrad_epilogue<BM, BN, WM, WN>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
+  dgrad_epilogue<BM, BN, WM, WN, BN == 64>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
     if (st == 1) return mrow;
     const int n = mrow / HcWc;
     const int rem = mrow - n * HcWc;
@@ -1977,7 +1992,7 @@ __device__ __forceinline__ void pl_pipeline2(int n, LoadF&& load, StoreF&& store
 }
 
 // ---- fprop ------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NBUF, int NP = 3>
+template <int BM, int BN, int WM, int WN, int NBUF, int NP = 3, bool PRE = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_kernel(const float* __restrict__ x,
                                                                                       const unsigned short* __restrict__ wp,
                                                                                       float* __restrict__ y, Geom g, int NT, Work wk,
@@ -2037,8 +2052,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
   constexpr int NSET = NBUF;           // two stages: two register sets (pl_pipeline2)
   float4 ra[NSET][AP];
   u32x4 rb[NSET][NP * BPP];
+  // PRE: the activation operand is the RAW output of the producing conv; its BatchNorm + ReLU (scale / shift of this thread's 4
+  // K-channels) is applied between the load and the split.  Halo / clip-end / ragged lanes must stay zero: their validity travels
+  // with the register set (pvalid).
+  float4 psc[PRE ? NSET : 1], psh[PRE ? NSET : 1];
+  unsigned pvalid[PRE ? NSET : 1];
   auto load = [&](auto set) __attribute__((always_inline)) {
     constexpr int SET = decltype(set)::value;
+    if constexpr (PRE) {
+      psc[SET] = *reinterpret_cast<const float4*>(epi.pre_scale + chunk * BK + 4 * kg);
+      psh[SET] = *reinterpret_cast<const float4*>(epi.pre_shift + chunk * BK + 4 * kg);
+      pvalid[SET] = 0u;
+    }
     const int cls = shift_class(chunk * BK + 4 * kg, g.fold);
     const int koff_a = ((r * g.W + s) * g.Cin + chunk * BK) * 4;
     const int koff_b = kt_w * g.Cout * 64;
@@ -2047,6 +2072,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
       const bool v = (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W &&
                      (unsigned)(a_t[p] + cls) < (unsigned)g.T;
       ra[SET][p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB), 0);
+      if constexpr (PRE) pvalid[SET] |= (v ? 1u : 0u) << p;
     }
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl)
@@ -2070,7 +2096,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
     unsigned char* const As = smem_b + stage * STAGE;
     unsigned char* const Bs = As + 3 * PA;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) pl_split_store_at<NP>(As + st_a + (NTHR / 8) * p * 64, PA, ra[SET][p]);
+    for (int p = 0; p < AP; ++p) {
+      float4 v = ra[SET][p];
+      if constexpr (PRE) {   // the same expression as bn_apply_kernel (fused multiply-add, then max): bit-identical activations
+        const bool ok = (pvalid[SET] >> p) & 1u;
+        v.x = ok ? fmaxf(fmaf(v.x, psc[SET].x, psh[SET].x), 0.f) : 0.f;
+        v.y = ok ? fmaxf(fmaf(v.y, psc[SET].y, psh[SET].y), 0.f) : 0.f;
+        v.z = ok ? fmaxf(fmaf(v.z, psc[SET].z, psh[SET].z), 0.f) : 0.f;
+        v.w = ok ? fmaxf(fmaf(v.w, psc[SET].w, psh[SET].w), 0.f) : 0.f;
+      }
+      pl_split_store_at<NP>(As + st_a + (NTHR / 8) * p * 64, PA, v);
+    }
     if (b_active) {
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl)
@@ -2315,7 +2351,8 @@ __device__ __forceinline__ bf16x8_t pl_frag_tr(const unsigned char* __restrict__
 template <int BM, int BN, int WM, int WN, bool INCR, int NP = 3, bool MTAP = false, int KW = 32>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                          float* __restrict__ slab, Geom g, int MTw, int NTw,
-                                                                         int kt_per_split) {
+                                                                         int kt_per_split, const float* __restrict__ pre_scale,
+                                                                         const float* __restrict__ pre_shift) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(TM >= 1 && TN >= 1 && (32 * (BM / 4)) % NTHR == 0 && (32 * (BN / 4)) % NTHR == 0, "tile / thread mapping");
@@ -2328,6 +2365,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
   constexpr int PLANE_A = KW * PITCH_A, PLANE_B = KW * PITCH_B;
   constexpr int STAGE = 3 * (PLANE_A + PLANE_B);
   __shared__ __attribute__((aligned(16))) unsigned char smem_b[NST * STAGE];
+  // pre_scale != null: x is the producer's RAW conv output; its BatchNorm + ReLU (per input channel) is applied between the load
+  // and the split (the same fused multiply-add as bn_apply_kernel).  The BN columns' scale / shift sit in LDS; halo / ragged
+  // lanes must stay zero, so their validity travels with the register set.
+  __shared__ __attribute__((aligned(16))) float pre_lds[2][BN];
+  const bool pre = pre_scale != nullptr;
 
   // slice-major, XCD-contiguous work order: all tiles of one K slice read the same rows of dy and x (see conv_wgrad_kernel)
   const int tiles = MTw * NTw;
@@ -2368,6 +2410,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
     b_off[p] = ((b_r[p] * g.W + b_s[p]) * g.Cin + ci) * 4 + b_cls[p] * frame_bytes;
   }
 
+  if (pre) {
+    for (int j = tid; j < BN; j += NTHR) {
+      const int col = nt * BN + j;
+      const int tapj = MTAP ? col / g.Cin : (nt * BN) / g.Cin;
+      const int cj = col - tapj * g.Cin;
+      pre_lds[0][j] = pre_scale[cj];
+      pre_lds[1][j] = pre_shift[cj];
+    }
+    __syncthreads();
+  }
   // kt counts KW-pixel steps (kt_per_split is given in 32-pixel steps)
   const int kt_begin = split * kt_per_split * NST;
   const int nkt_all = (g.M + KW - 1) / KW;
@@ -2397,11 +2449,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
   }
 
   float4 ra[NST][AP], rb[NST][BP];
+  unsigned bvalid[NST];
   int kt_load = kt_begin;           // load(set) fetches the next step in order
   auto load = [&](auto set) __attribute__((always_inline)) {
     constexpr int SET = decltype(set)::value;
     const int m0 = kt_load * KW;
     kt_load += 1;
+    bvalid[SET] = 0u;
 #pragma unroll
     for (int p = 0; p < AP; ++p)  // rows past M lie past num_records: zeros
       ra[SET][p] = buf_load16(yr, a_off[p] + m0 * g.Cout * 4, 0);
@@ -2437,6 +2491,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
       const bool v = mok && (unsigned)(hi + b_r[p]) < (unsigned)g.H && (unsigned)(wi_ + b_s[p]) < (unsigned)g.W &&
                      (unsigned)(t * g.st_t + b_cls[p]) < (unsigned)(g.T * g.st_t);
       rb[SET][p] = buf_load16(xr, off | (v ? 0 : kOOB), 0);
+      bvalid[SET] |= (v ? 1u : 0u) << p;
     }
   };
 
@@ -2450,7 +2505,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
 #pragma unroll
     for (int p = 0; p < AP; ++p) pl_store_rows<BM, NP, KW>(As, a_krow[p], (tid + NTHR * p) % AV, ra[SET][p]);
 #pragma unroll
-    for (int p = 0; p < BP; ++p) pl_store_rows<BN, NP, KW>(Bs, b_krow[p], (tid + NTHR * p) % BV, rb[SET][p]);
+    for (int p = 0; p < BP; ++p) {
+      const int c4 = (tid + NTHR * p) % BV;
+      float4 v = rb[SET][p];
+      if (pre) {
+        const float4 sc = *reinterpret_cast<const float4*>(&pre_lds[0][4 * c4]), sh = *reinterpret_cast<const float4*>(&pre_lds[1][4 * c4]);
+        const bool ok = (bvalid[SET] >> p) & 1u;
+        v.x = ok ? fmaxf(fmaf(v.x, sc.x, sh.x), 0.f) : 0.f;
+        v.y = ok ? fmaxf(fmaf(v.y, sc.y, sh.y), 0.f) : 0.f;
+        v.z = ok ? fmaxf(fmaf(v.z, sc.z, sh.z), 0.f) : 0.f;
+        v.w = ok ? fmaxf(fmaf(v.w, sc.w, sh.w), 0.f) : 0.f;
+      }
+      pl_store_rows<BN, NP, KW>(Bs, b_krow[p], c4, v);
+    }
   };
   auto mma = [&](int stage) __attribute__((always_inline)) {
     const unsigned char* const As = smem_b + stage * STAGE;
@@ -2796,6 +2863,14 @@ int pl_dgrad_cfg(const bdv_conv_geom* g, int pieces = 3) {
   return pl_pick(true, g->Cin, g->R * g->S * g->Cout / BK, g->R * g->S, g->stride, pieces, g->fold > 0);
 }
 bool pl_fprop_ok(const bdv_conv_geom* g, int pieces = 3) { return pl_fprop_cfg(g, pieces) >= 0; }
+// plane-kernel tile of a site whose input BatchNorm the loader applies (pre_scale): the planner's choice, or the widest tile that
+// divides the column count where the planner would have used a kernel that cannot do it
+int pl_fprop_cfg_pre(const bdv_conv_geom* g) {
+  if (g->Cin % BK != 0 || g->Cout % 64 != 0) return -1;
+  const int cfg = pl_fprop_cfg(g, 3);
+  if (cfg >= 0) return cfg;
+  return g->Cout % 256 == 0 ? 0 : g->Cout % 128 == 0 ? 1 : 3;
+}
 bool pl_dgrad_ok(const bdv_conv_geom* g, int pieces = 3) { return pl_dgrad_cfg(g, pieces) >= 0; }
 
 
@@ -2932,8 +3007,8 @@ extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
   size_t need = p.wk.split > 1 ? (size_t)p.wk.rem_tiles * p.wk.split * p.seg_bytes : 0;
   // the P kernels (bdv_conv_fprop_pl / bdv_conv_dgrad_pl) plan their own K-split
   for (int pieces = 1; pieces <= 3; pieces += 2) {
-    if (kind == 0 && pl_fprop_ok(gg, pieces)) {
-      const PlPlan q = plan_pl(pl_fprop_cfg(gg, pieces), g.M, g.Cout, g.Ktot / BK, kMaxSplitWorkspace, true);
+    if (kind == 0 && (pl_fprop_ok(gg, pieces) || (pieces == 3 && pl_fprop_cfg_pre(gg) >= 0))) {
+      const PlPlan q = plan_pl(pl_fprop_ok(gg, pieces) ? pl_fprop_cfg(gg, pieces) : pl_fprop_cfg_pre(gg), g.M, g.Cout, g.Ktot / BK, kMaxSplitWorkspace, true);
       const size_t n2 = q.wk.split > 1 ? (size_t)q.wk.rem_tiles * q.wk.split * q.seg_bytes : 0;
       need = n2 > need ? n2 : need;
     } else if (kind == 1 && pl_dgrad_ok(gg, pieces) && gg->stride == 1) {
@@ -3040,7 +3115,7 @@ int conv_dgrad_impl(const float* dy, const float* w, const float* w_t, float* dx
                     const uint32_t* add_mask_src, const bdv_conv_geom* gg, const bdv_bn_stat_fuse* bn_stat, void* workspace,
                     size_t workspace_bytes, void* stream, const void* planes_d = nullptr) {
   if (int e = check_geom(gg, "bdv_conv_dgrad")) return e;
-  BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
   if (bn_stat != nullptr) {
     BDV_REQUIRE(gg->stride == 1 || (gg->R >= gg->stride && gg->S >= gg->stride),
                 "bdv_conv_dgrad: fused BatchNorm statistics with stride 2 need a filter that reaches every input pixel (R, S >= 2)");
@@ -3053,7 +3128,11 @@ int conv_dgrad_impl(const float* dy, const float* w, const float* w_t, float* dx
     stat.mean = bn_stat->mean;
     stat.invstd = bn_stat->invstd;
     stat.partial = bn_stat->partial;
+    stat.rscale = bn_stat->relu_mask == nullptr ? bn_stat->relu_scale : nullptr;
+    stat.rshift = bn_stat->relu_shift;
     stat.MT = bdv_conv_dgrad_stat_rows(gg);
+    BDV_REQUIRE(stat.rscale == nullptr || w_t != nullptr || planes_d != nullptr || gg->Cin % 128 != 0,
+                "bdv_conv_dgrad: a ReLU sign derived from y (relu_scale) is not compiled into the 128-wide fp32-MFMA kernel");
     if (gg->stride != 1)  // parity classes of odd-sized inputs have fewer row tiles than the largest: their rows stay zero
       (void)hipMemsetAsync(bn_stat->partial, 0, (size_t)2 * stat.MT * gg->Cin * sizeof(float), (hipStream_t)stream);
   }
@@ -3177,6 +3256,14 @@ extern "C" int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* gg, int pieces) 
   return p.cfg >= 0 ? p.MT : 0;
 }
 
+extern "C" int bdv_conv_fprop_pre_stat_rows(const bdv_conv_geom* gg) {
+  if (check_geom(gg, "bdv_conv_fprop_pre_stat_rows")) return 0;
+  const int cfg = pl_fprop_cfg_pre(gg);
+  if (cfg < 0) return 0;
+  const PlPlan p = plan_pl(cfg, gg->N * gg->Ho * gg->Wo, gg->Cout, gg->R * gg->S * gg->Cin / BK, kMaxSplitWorkspace, true);
+  return p.MT;
+}
+
 extern "C" int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* gg, int pieces) {
   if (check_geom(gg, "bdv_conv_dgrad_pl_stat_rows")) return 0;
   if (!pl_dgrad_ok(gg, pieces)) return bdv_conv_dgrad_stat_rows(gg);
@@ -3199,16 +3286,27 @@ extern "C" int bdv_conv_split_weights(const float* w, const bdv_conv_geom* gg, v
   return BDV_OK;
 }
 
+extern "C" int bdv_conv_fprop_pre_ok(const bdv_conv_geom* gg) {
+  if (check_geom(gg, "bdv_conv_fprop_pre_ok")) return 0;
+  return pl_fprop_cfg_pre(gg) >= 0 && gg->fold == 0 ? 1 : 0;
+}
+
 extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* planes_fprop, float* y, const bdv_conv_geom* gg,
                                  float* bn_partial, const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes,
-                                 int pieces, void* stream) {
+                                 int pieces, const float* pre_scale, const float* pre_shift, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_fprop_pl")) return e;
   BDV_REQUIRE(pieces == 3 || pieces == 1, "bdv_conv_fprop_pl: pieces = %d (3 or 1)", pieces);
-  if (planes_fprop == nullptr || !pl_fprop_ok(gg, pieces))  // sites of the two-workgroups-per-CU kernels (weights from the planes too)
+  const bool pre = pre_scale != nullptr;
+  if (pre) {
+    BDV_REQUIRE(pre_shift != nullptr && planes_fprop != nullptr && pieces == 3 && gg->fold == 0 && pl_fprop_cfg_pre(gg) >= 0,
+                "bdv_conv_fprop_pl: a producer BatchNorm in the loader needs the plane kernels (pieces 3, no temporal shift, Cin %% 32 == 0)");
+    BDV_REQUIRE(bdv_aligned16(pre_scale) && bdv_aligned16(pre_shift), "bdv_conv_fprop_pl: pre_scale / pre_shift must be 16-byte aligned");
+  }
+  if (!pre && (planes_fprop == nullptr || !pl_fprop_ok(gg, pieces)))  // sites of the two-workgroups-per-CU kernels (weights from the planes too)
     return conv_fprop_impl(x, w, y, gg, bn_partial, affine, workspace, workspace_bytes, stream, true,
                            gg->Cin % BK == 0 && r1_planes_enabled() ? planes_fprop : nullptr);
   BDV_REQUIRE(x && y, "bdv_conv_fprop_pl: null pointer");
-  FpropEpi epi = {bn_partial, 0, nullptr, nullptr, nullptr, 0};
+  FpropEpi epi = {bn_partial, 0, nullptr, nullptr, nullptr, 0, pre_scale, pre_shift};
   if (affine != nullptr) {
     BDV_REQUIRE(bn_partial == nullptr, "bdv_conv_fprop_pl: batch statistics and the folded eval-mode BatchNorm exclude each other");
     BDV_REQUIRE(affine->scale && affine->shift, "bdv_conv_fprop_pl: null pointer in bdv_conv_affine");
@@ -3226,7 +3324,7 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
   g.Ktot = g.Rt * g.R * g.S * g.Cin;
   BDV_REQUIRE((int64_t)3 * g.Cout * g.Ktot * 2 < (1ll << 31), "bdv_conv_fprop_pl: weight planes exceed 2^31 bytes");
   hipStream_t s = (hipStream_t)stream;
-  const PlPlan p = plan_pl(pl_fprop_cfg(gg, pieces), g.M, g.Cout, g.Ktot / BK, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, true);
+  const PlPlan p = plan_pl(pre ? pl_fprop_cfg_pre(gg) : pl_fprop_cfg(gg, pieces), g.M, g.Cout, g.Ktot / BK, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, true);
   BDV_REQUIRE(p.cfg >= 0, "bdv_conv_fprop_pl: no tile configuration for Cout=%d", g.Cout);
   // bn_partial has one row per row tile of THIS kernel: bdv_conv_fprop_pl_stat_rows(g)
   const int blocks = p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split;
@@ -3238,7 +3336,10 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
             g.W, g.Cin, g.Cout, g.R, g.stride, p.cfg, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split, p.est_us);
 #define BDV_FPROP_PL(BM_, BN_, WM_, WN_, NB_)                                                                                         \
   do {                                                                                                                                \
-    if (pieces == 1)                                                                                                                  \
+    if (pre)                                                                                                                          \
+      hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_, 3, true>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y,  \
+                         g, p.NT, p.wk, slab, epi);                                                                                   \
+    else if (pieces == 1)                                                                                                             \
       hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_, 1>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y, g,    \
                          p.NT, p.wk, slab, epi);                                                                                      \
     else                                                                                                                              \
@@ -3267,7 +3368,7 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
   if (planes_dgrad == nullptr || !pl_dgrad_ok(gg, pieces))
     return conv_dgrad_impl(dy, w, nullptr, dx, add_src, add_mask_src, gg, bn_stat, workspace, workspace_bytes, stream,
                            gg->Cout % BK == 0 && r1_planes_enabled() ? planes_dgrad : nullptr);
-  BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
   if (bn_stat != nullptr) {
     BDV_REQUIRE(gg->stride == 1 || (gg->R >= gg->stride && gg->S >= gg->stride),
                 "bdv_conv_dgrad_pl: fused BatchNorm statistics with stride 2 need a filter that reaches every input pixel (R, S >= 2)");
@@ -3280,6 +3381,8 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
     stat.mean = bn_stat->mean;
     stat.invstd = bn_stat->invstd;
     stat.partial = bn_stat->partial;
+    stat.rscale = bn_stat->relu_mask == nullptr ? bn_stat->relu_scale : nullptr;
+    stat.rshift = bn_stat->relu_shift;
   }
   BDV_REQUIRE(dy && dx, "bdv_conv_dgrad_pl: null pointer");
   BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(planes_dgrad) && bdv_aligned16(dx) && bdv_aligned16(workspace),
@@ -3426,9 +3529,16 @@ extern "C" int bdv_conv_wgrad_pl_splits(const bdv_conv_geom* gg) {
   return pl_wgrad_ok(gg) ? plan_wgrad_pl(gg).splits : plan_wgrad(gg).splits;
 }
 
+extern "C" int bdv_conv_wgrad_pre_ok(const bdv_conv_geom* gg) {
+  if (check_geom(gg, "bdv_conv_wgrad_pre_ok")) return 0;
+  return pl_wgrad_ok(gg) && gg->Cin % BK == 0 && gg->fold == 0 ? 1 : 0;
+}
+
 extern "C" int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const bdv_conv_geom* gg, void* slab, size_t slab_bytes,
-                                         int pieces, void* stream) {
+                                         int pieces, const float* pre_scale, const float* pre_shift, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_wgrad_partial_pl")) return e;
+  BDV_REQUIRE(pre_scale == nullptr || (pre_shift != nullptr && pl_wgrad_ok(gg) && gg->Cin % BK == 0 && gg->fold == 0),
+              "bdv_conv_wgrad_partial_pl: a producer BatchNorm in the loader needs the plane kernel, Cin %% 32 == 0 and no temporal shift");
   BDV_REQUIRE(pieces == 3 || pieces == 1, "bdv_conv_wgrad_partial_pl: pieces = %d (3 or 1)", pieces);
   BDV_REQUIRE(dy && x && slab, "bdv_conv_wgrad_partial_pl: null pointer");
   BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(slab), "bdv_conv_wgrad_partial_pl: pointers must be 16-byte aligned");
@@ -3453,7 +3563,7 @@ extern "C" int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const 
   const bool incr = g.Ho * g.Wo > BK && BK / g.Wo + 1 <= g.Ho;
 #define BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, INCR_, NP_, MTAP_, KW_)                                                                \
   hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, WM_, WN_, INCR_, NP_, MTAP_, KW_>), grid, dim3(64 * WM_ * WN_), 0, s, dy, x, \
-                     (float*)slab, g, p.MTw, p.NTw, p.kt_per_split)
+                     (float*)slab, g, p.MTw, p.NTw, p.kt_per_split, pre_scale, pre_shift)
 #define BDV_WGRAD_PL(BM_, BN_, WM_, WN_, MTAP_, KW_)                                                                             \
   do {                                                                                                                           \
     if (incr && pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 3, MTAP_, KW_);                                             \

@@ -38,6 +38,15 @@ _SIDE = {'enabled': _os.environ.get('BDVCIL_WGRAD_SIDE_STREAM', '1') != '0', 'st
 # BatchNorm-backward statistics of a unit taken in the epilogue of the dgrad that produces its output gradient
 # (bdv_conv_dgrad with a bdv_bn_stat_fuse): removes the separate pass over dout, y and the mask for the inner units.
 FUSE_BN_STATS = _os.environ.get('BDVCIL_FUSE_BN_STATS', '1') != '0'
+# A unit's BatchNorm + ReLU applied in the loaders of the conv that consumes it (fprop and weight gradient) instead of in an apply
+# pass of its own: conv1 -> conv2 and conv2 -> conv3 inside a block (the block output is read by two consumers and stays a pass).
+# The activation and its ReLU mask are then never written; the backward kernels derive the sign from the conv output.
+PRE_BN = _os.environ.get('BDVCIL_PRE_BN', '0') == '1'      # off: measured 0.6 ms per step SLOWER; saves ~2.8 GB
+# The forward half of it alone: the consumer conv applies the producer's BatchNorm + ReLU in its loader and starts right away, while
+# the apply pass that writes the activation and the mask for the BACKWARD pass runs beside it on the side stream (an HBM-bound pass
+# beside an MFMA-bound conv).  The backward pass is the default one.  BDVCIL_PRE_BN=fwd.
+PRE_BN_FWD = _os.environ.get('BDVCIL_PRE_BN', '0') == 'fwd'
+SAVED_PER_UNIT = 7      # y, activation | None, mean, invstd, mask | None, scale | None, shift | None
 # A whole stage as one autograd node (ResStageFn): lets the statistics fusion above reach the block outputs.
 FUSE_STAGE = _os.environ.get('BDVCIL_FUSE_STAGE', '1') != '0'
 # one split-K reduction launch per autograd node (stage / block) instead of one per conv
@@ -107,16 +116,26 @@ class wgrad_batch:
         return False
 
 
-def wgrad_overlapped(dy: torch.Tensor, inp: torch.Tensor, geom) -> torch.Tensor:
+# How the weight gradient of a conv gets its activation operand when the producer's apply pass never ran (PRE_BN):
+# 'recompute' (default): one bn_apply on the stream the weight gradient runs on (the side stream: an HBM-bound pass beside the
+# main chain's MFMA-bound dgrads), then the plain kernel; 'loader': the producer's BatchNorm + ReLU in the weight-gradient kernel's
+# own loader (measured slower in the step: that loader already splits both operands).
+PRE_BN_WGRAD = _os.environ.get('BDVCIL_PRE_BN_WGRAD', 'recompute')
+
+
+def wgrad_overlapped(dy: torch.Tensor, inp: torch.Tensor, geom, pre_bn=None) -> torch.Tensor:
     """Weight gradient of one conv: deferred reduction inside a ``wgrad_batch``, otherwise K.conv_wgrad (optionally on the
     side stream)."""
     batch = wgrad_batch.current
+    recompute = pre_bn is not None and PRE_BN_WGRAD != 'loader'
     if not _SIDE['enabled']:
+        if recompute:
+            inp, pre_bn = K.bn_apply(inp, pre_bn[0], pre_bn[1], None, True), None
         if batch is not None:
-            slab, dw = K.conv_wgrad_partial(dy, inp, geom)
+            slab, dw = K.conv_wgrad_partial(dy, inp, geom, pre_bn=pre_bn)
             batch.items.append((slab, dw))
             return dw
-        return K.conv_wgrad(dy, inp, geom)
+        return K.conv_wgrad(dy, inp, geom, pre_bn=pre_bn)
     main = torch.cuda.current_stream(dy.device)
     idx, side = _side_stream(dy.device)
     dw = torch.empty((geom.Cout, geom.R, geom.S, geom.Cin), dtype=torch.float32, device=dy.device)   # owned by main
@@ -124,11 +143,14 @@ def wgrad_overlapped(dy: torch.Tensor, inp: torch.Tensor, geom) -> torch.Tensor:
     ready.record(main)
     side.wait_event(ready)
     with torch.cuda.stream(side):
+        if recompute:               # the activation exists only for the duration of this weight gradient
+            inp = K.bn_apply(inp, pre_bn[0], pre_bn[1], None, True)
+            pre_bn = None
         if batch is not None:       # split-K slabs now, one reduction launch (on the side stream) when the stage ends
-            slab, _ = K.conv_wgrad_partial(dy, inp, geom, dw=dw)
+            slab, _ = K.conv_wgrad_partial(dy, inp, geom, dw=dw, pre_bn=pre_bn)
             batch.items.append((slab, dw))
         else:
-            K.conv_wgrad(dy, inp, geom, dw=dw, beta=0.0, ws_tag='wgrad_side')
+            K.conv_wgrad(dy, inp, geom, dw=dw, beta=0.0, ws_tag='wgrad_side', pre_bn=pre_bn)
         done = torch.cuda.Event()
         done.record(side)
     for t in (dy, inp, dw):
@@ -230,14 +252,15 @@ class TemporalUnitSpec(UnitSpec):
         return H, W
 
 
-def _conv_bn_forward(x, w_krsc, g, bn, gamma, beta, training):
+def _conv_bn_forward(x, w_krsc, g, bn, gamma, beta, training, pre_bn=None):
     """conv + BatchNorm statistics -> (y, mean, invstd, scale, shift) in training mode: the batch statistics come out
-    of the conv epilogue (no extra pass over y) and running stats are updated in place."""
+    of the conv epilogue (no extra pass over y) and running stats are updated in place.  ``pre_bn``: (scale, shift) of the
+    producing unit when x is its raw conv output (its BatchNorm + ReLU is applied in this conv's loader)."""
     if bn.momentum is None:
         raise NotImplementedError('BatchNorm momentum=None (cumulative average) is not supported by the HIP path')
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    y, part = K.conv_fprop(x, w_krsc, g, bn_stats=True)
+    y, part = K.conv_fprop(x, w_krsc, g, bn_stats=True, pre_bn=pre_bn)
     mean, invstd, scale, shift = K.bn_train_finalize(part, g.N * g.Ho * g.Wo, gamma, beta, bn.eps, bn.momentum, rm, rv)
     return y, mean, invstd, scale, shift
 
@@ -249,10 +272,12 @@ def _conv_bn_eval(x, w_krsc, g, bn, gamma, beta, res, relu):
     return K.conv_fprop(x, w_krsc, g, affine=(scale, shift, res, relu))
 
 
-def _bn_wgrad_backward(dout, mask, y, gamma, mean, invstd, inp, geom, need_dw, stat_partial=None):
-    """BatchNorm(+ReLU) backward of one conv+BN unit followed by the conv's wgrad -> (dy, dgamma, dbeta, dw | None)."""
-    dy, dg, db = K.bn_backward(dout, mask, y, gamma, mean, invstd, True, stat_partial=stat_partial)
-    dw = wgrad_overlapped(dy, inp, geom) if need_dw else None
+def _bn_wgrad_backward(dout, mask, y, gamma, mean, invstd, inp, geom, need_dw, stat_partial=None, relu_affine=None, pre_bn=None):
+    """BatchNorm(+ReLU) backward of one conv+BN unit followed by the conv's wgrad -> (dy, dgamma, dbeta, dw | None).
+    ``relu_affine``: (scale, shift) of THIS unit when its mask was never written (the sign is derived from y);
+    ``pre_bn``: (scale, shift) of the unit that produced ``inp`` when ``inp`` is that unit's raw conv output."""
+    dy, dg, db = K.bn_backward(dout, mask, y, gamma, mean, invstd, True, stat_partial=stat_partial, relu_affine=relu_affine)
+    dw = wgrad_overlapped(dy, inp, geom, pre_bn=pre_bn) if need_dw else None
     return dy, dg, db, dw
 
 
@@ -333,6 +358,8 @@ def _block_forward(x, blk, training, params, save):
     else:
         identity, id_affine = x, None
     cur = x
+    side_events = []        # apply passes running on the side stream (PRE_BN_FWD): joined before the block returns
+    pending = None          # (scale, shift) of the previous unit when `cur` is its raw conv output
     h, w_ = H, W
     for i in range(n_main):
         u = units[i]
@@ -344,20 +371,47 @@ def _block_forward(x, blk, training, params, save):
             h, w_ = u.out_hw(h, w_)
             cur = _conv_bn_eval(cur, weight_krsc(wt), g, bns[i], gm, bt, identity if last else None, True).view(N, h, w_, u.cout)
             continue
-        y, mean, invstd, sc, sh = _conv_bn_forward(cur, weight_krsc(wt), g, bns[i], gm, bt, training)
+        y, mean, invstd, sc, sh = _conv_bn_forward(cur, weight_krsc(wt), g, bns[i], gm, bt, training, pre_bn=pending)
         y = y.view(N, *u.out_hw(h, w_), u.cout)          # frames view (a temporal geometry describes another view of it)
         if last and has_down and training and ds_event is not None:
             torch.cuda.current_stream(x.device).wait_event(ds_event)      # the identity branch is needed from here on
-        if save:
-            a, mask = K.bn_apply(y, sc, sh, identity if last else None, True, want_mask=True,
-                                 res_affine=id_affine if last else None)
-            saved += [y, a, mean, invstd, mask]
+        h2, w2 = u.out_hw(h, w_)
+        # the next unit of the main branch can apply this unit's BatchNorm + ReLU in its own loaders: no apply pass here
+        can_pre = not last and (PRE_BN or PRE_BN_FWD) and K.fprop_pre_ok(units[i + 1].geom(N, h2, w2))
+        defer = can_pre and PRE_BN
+        if can_pre and not defer and save and _SIDE['enabled'] and y.is_cuda:
+            # forward-only form: the next conv reads the raw output; activation + mask for the backward pass come from the side stream
+            (a, mask), ev = run_on_side_stream(lambda: K.bn_apply(y, sc, sh, None, True, want_mask=True), y.device)
+            side = _side_stream(y.device)[1]
+            for t in (y, sc, sh):
+                t.record_stream(side)
+            main = torch.cuda.current_stream(y.device)
+            a.record_stream(main)
+            mask.record_stream(main)
+            side_events.append(ev)
+            saved += [y, a, mean, invstd, mask, None, None]
             if RELU_MASK_TAP is not None:
                 RELU_MASK_TAP.append((tuple(y.shape), mask))
+            cur, pending = y, (sc, sh)
+        elif defer:
+            if RELU_MASK_TAP is not None:       # tests read every ReLU's sign bits: produce them on the side
+                RELU_MASK_TAP.append((tuple(y.shape), K.bn_apply(y, sc, sh, None, True, want_mask=True)[1]))
+            if save:
+                saved += [y, None, mean, invstd, None, sc, sh]
+            cur, pending = y, (sc, sh)
         else:
-            a = K.bn_apply(y, sc, sh, identity if last else None, True, res_affine=id_affine if last else None)
-        cur = a
-        h, w_ = u.out_hw(h, w_)
+            if save:
+                a, mask = K.bn_apply(y, sc, sh, identity if last else None, True, want_mask=True,
+                                     res_affine=id_affine if last else None)
+                saved += [y, a, mean, invstd, mask, None, None]
+                if RELU_MASK_TAP is not None:
+                    RELU_MASK_TAP.append((tuple(y.shape), mask))
+            else:
+                a = K.bn_apply(y, sc, sh, identity if last else None, True, res_affine=id_affine if last else None)
+            cur, pending = a, None
+        h, w_ = h2, w2
+    for ev in side_events:  # (long finished by now: an apply pass is a tenth of the conv that ran beside it)
+        torch.cuda.current_stream(x.device).wait_event(ev)
     if save and has_down:
         saved += [yd, mean_d, invstd_d]
         geoms.append(units[n_main].geom(N, H, W))
@@ -368,7 +422,8 @@ def _block_out_stats(saved, n_main):
     """(y, mask, mean, invstd) of a block's last main unit: what a dgrad epilogue needs to take the BatchNorm-backward
     statistics of the gradient it writes into that block's output."""
     k = n_main - 1
-    return saved[1 + 5 * k], saved[5 + 5 * k], saved[3 + 5 * k], saved[4 + 5 * k]
+    q = SAVED_PER_UNIT * k
+    return saved[1 + q], saved[5 + q], saved[3 + q], saved[4 + q]
 
 
 def _block_backward(saved, params, geoms, n_main, has_down, dout, need_params, need_dx, out_stat_partial=None,
@@ -378,11 +433,14 @@ def _block_backward(saved, params, geoms, n_main, has_down, dout, need_params, n
     operands of the PREVIOUS block's last unit; the dgrad that writes dx then reduces them in its epilogue.
     Returns (dx, parameter gradients, partial for the previous block | None)."""
     x = saved[0]
-    ys = [saved[1 + 5 * i] for i in range(n_main)]
-    acts = [saved[2 + 5 * i] for i in range(n_main)]
-    means = [saved[3 + 5 * i] for i in range(n_main)]
-    invstds = [saved[4 + 5 * i] for i in range(n_main)]
-    masks = [saved[5 + 5 * i] for i in range(n_main)]
+    Q = SAVED_PER_UNIT
+    ys = [saved[1 + Q * i] for i in range(n_main)]
+    acts = [saved[2 + Q * i] for i in range(n_main)]
+    means = [saved[3 + Q * i] for i in range(n_main)]
+    invstds = [saved[4 + Q * i] for i in range(n_main)]
+    masks = [saved[5 + Q * i] for i in range(n_main)]
+    # units whose apply pass never ran (PRE_BN): (scale, shift) instead of an activation and a mask
+    affs = [(saved[6 + Q * i], saved[7 + Q * i]) if saved[6 + Q * i] is not None else None for i in range(n_main)]
     out_mask = masks[-1]
     dout = dout if dout.is_contiguous() else dout.contiguous()
     grads: List[Optional[torch.Tensor]] = [None] * len(params)
@@ -391,9 +449,10 @@ def _block_backward(saved, params, geoms, n_main, has_down, dout, need_params, n
     d, part = dout, out_stat_partial
     for i in range(n_main - 1, -1, -1):
         wt, gm = params[3 * i], params[3 * i + 1]
-        inp = acts[i - 1] if i > 0 else x
+        # this conv's input: the previous unit's activation, or its raw conv output + (scale, shift) for the loader
+        inp = (acts[i - 1] if affs[i - 1] is None else ys[i - 1]) if i > 0 else x
         dy, dg, db, dw = _bn_wgrad_backward(d, masks[i], ys[i], gm, means[i], invstds[i], inp, geoms[i], need_params[3 * i],
-                                            stat_partial=part)
+                                            stat_partial=part, relu_affine=affs[i], pre_bn=affs[i - 1] if i > 0 else None)
         grads[3 * i + 1], grads[3 * i + 2] = dg, db
         if dw is not None:
             grads[3 * i] = grad_like_weight(dw, wt)
@@ -403,7 +462,8 @@ def _block_backward(saved, params, geoms, n_main, has_down, dout, need_params, n
             if FUSE_BN_STATS and (gi.stride == 1 or (gi.R > 1 and gi.S > 1 and gi.fold == 0)):
                 # this dgrad produces the gradient entering unit i-1's BN+ReLU: take its statistics in the epilogue
                 # (stride 2: a 3x3 filter reaches every input pixel, one block of partial rows per parity class)
-                d, part = K.conv_dgrad(dy, weight_krsc(wt), gi, bn_stats=(ys[i - 1], masks[i - 1], means[i - 1], invstds[i - 1]))
+                prev = (ys[i - 1], masks[i - 1], means[i - 1], invstds[i - 1])
+                d, part = K.conv_dgrad(dy, weight_krsc(wt), gi, bn_stats=prev if affs[i - 1] is None else prev + (affs[i - 1],))
             else:
                 d = K.conv_dgrad(dy, weight_krsc(wt), gi)
             d = d.view_as(inp)                     # frames view (the geometry of a temporal conv names another view)
@@ -413,7 +473,7 @@ def _block_backward(saved, params, geoms, n_main, has_down, dout, need_params, n
     dx, prev_partial = None, None
     stats = prev_stats if (FUSE_BN_STATS and prev_stats is not None and geoms[0].stride == 1) else None
     if has_down:
-        yd, mean_d, invstd_d = saved[1 + 5 * n_main:4 + 5 * n_main]
+        yd, mean_d, invstd_d = saved[1 + SAVED_PER_UNIT * n_main:4 + SAVED_PER_UNIT * n_main]
         wd, gd = params[3 * n_main], params[3 * n_main + 1]
         gdn = geoms[n_main]
         # gradient entering the downsample BN is dout * (out > 0): same mask as the block output

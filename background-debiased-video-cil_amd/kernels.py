@@ -244,12 +244,22 @@ def conv_kernel_name(g: ConvGeom, kind: str, x3: Optional[bool] = None) -> str:
     return buf.value.decode()
 
 
+def fprop_pre_ok(g: ConvGeom) -> bool:
+    """True when ``conv_fprop(pre_bn=...)`` and ``conv_wgrad*(pre_bn=...)`` can apply the producer's BatchNorm + ReLU in their
+    loaders for this geometry (bf16-piece arithmetic with the plane kernels; no temporal shift)."""
+    return bool(PIECES == 3 and FPROP_X3 and WGRAD_X3 and DGRAD_X3 and USE_PL and USE_PL_WGRAD and g.fold == 0 and g.Rt <= 1
+                and not getattr(g, 'frames_view', False)
+                and lib().bdv_conv_fprop_pre_ok(ctypes.byref(g)) and lib().bdv_conv_wgrad_pre_ok(ctypes.byref(g)))
+
+
 def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torch.Tensor] = None,
-               ws_tag: str = 'conv', bn_stats: bool = False, affine=None, x3: Optional[bool] = None):
+               ws_tag: str = 'conv', bn_stats: bool = False, affine=None, x3: Optional[bool] = None, pre_bn=None):
     """x (N,H,W,Cin) NHWC, w (Cout,R,S,Cin) -> y (N,Ho,Wo,Cout); with bn_stats also the fused BatchNorm partial
     sums (float[2][rows][Cout]) for ``bn_train_finalize``.
     ``affine = (scale, shift, residual | None, relu)``: eval-mode BatchNorm folded into the epilogue,
-    y = relu?(conv * scale + shift (+ residual))."""
+    y = relu?(conv * scale + shift (+ residual)).
+    ``pre_bn = (scale, shift)``: x is the RAW output of the producing conv; its train-mode BatchNorm + ReLU is applied in the
+    loader (``fprop_pre_ok(g)``), so no apply pass / activation / mask is needed for this consumer."""
     _chk_conv(x, (_in_frames(g), g.H, g.W, g.Cin), g, 'x')
     _chk(w, (g.Cout, _taps_r(g), g.S, g.Cin), name='w')
     y = out if out is not None else torch.empty((g.N, g.Ho, g.Wo, g.Cout), dtype=torch.float32, device=x.device)
@@ -258,10 +268,17 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
     part = aff = None
     use_x3 = FPROP_X3 if x3 is None else x3
     use_pl = bool(use_x3 and USE_PL and lib().bdv_conv_uses_planes(ctypes.byref(g), 0, PIECES))
+    if pre_bn is not None:
+        if not (use_x3 and USE_PL and PIECES == 3 and lib().bdv_conv_fprop_pre_ok(ctypes.byref(g))):
+            raise ValueError('conv_fprop: pre_bn needs the bf16-piece plane kernels for this geometry (fprop_pre_ok)')
+        _chk(pre_bn[0], (g.Cin,), name='pre_scale')
+        _chk(pre_bn[1], (g.Cin,), name='pre_shift')
+        use_pl = True
     if bn_stats:
         if affine is not None:
             raise ValueError('conv_fprop: bn_stats and affine exclude each other')
-        rows = lib().bdv_conv_fprop_pl_stat_rows(ctypes.byref(g), PIECES) if use_pl else lib().bdv_conv_fprop_stat_rows(ctypes.byref(g))
+        rows = lib().bdv_conv_fprop_pre_stat_rows(ctypes.byref(g)) if pre_bn is not None else \
+            lib().bdv_conv_fprop_pl_stat_rows(ctypes.byref(g), PIECES) if use_pl else lib().bdv_conv_fprop_stat_rows(ctypes.byref(g))
         if rows <= 0:
             check(-1, 'bdv_conv_fprop_stat_rows')
         part = torch.empty((2, rows, g.Cout), dtype=torch.float32, device=x.device)
@@ -275,8 +292,9 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
     if use_pl:
         planes_f, _ = weight_planes(w, g)
         check(lib().bdv_conv_fprop_pl(_p(x), _p(w), _p(planes_f), _p(y), ctypes.byref(g), _p(part),
-                                      ctypes.byref(aff) if aff is not None else None, _p(ws), ws.numel(), PIECES, _stream()),
-              'bdv_conv_fprop_pl')
+                                      ctypes.byref(aff) if aff is not None else None, _p(ws), ws.numel(), PIECES,
+                                      _p(pre_bn[0] if pre_bn is not None else None), _p(pre_bn[1] if pre_bn is not None else None),
+                                      _stream()), 'bdv_conv_fprop_pl')
         return (y, part) if bn_stats else y
     fn = lib().bdv_conv_fprop_x3 if use_x3 else lib().bdv_conv_fprop
     check(fn(_p(x), _p(w), _p(y), ctypes.byref(g), _p(part), ctypes.byref(aff) if aff is not None else None,
@@ -306,8 +324,12 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
     fuse = partial = None
     use_x3 = (DGRAD_X3 if x3 is None else x3) and g.Cin % 64 == 0
     use_pl = bool(use_x3 and USE_PL and lib().bdv_conv_uses_planes(ctypes.byref(g), 1, PIECES))
+    relu_affine = None
     if bn_stats is not None:
-        y, mask, mean, invstd = bn_stats
+        if len(bn_stats) == 5:      # (y, None, mean, invstd, (scale, shift)): the unit's ReLU sign is derived from y
+            y, mask, mean, invstd, relu_affine = bn_stats
+        else:
+            y, mask, mean, invstd = bn_stats
         _chk_conv(y, (g.N, g.H, g.W, g.Cin), g, 'y')
         _chk(mean, (g.Cin,), name='mean')
         _chk(invstd, (g.Cin,), name='invstd')
@@ -317,8 +339,14 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
         if rows <= 0:
             check(-1, 'bdv_conv_dgrad_stat_rows')
         partial = torch.empty((2, rows, g.Cin), dtype=torch.float32, device=dy.device)
+        if relu_affine is not None:
+            if mask is not None:
+                raise ValueError('conv_dgrad: a ReLU mask and a derived ReLU sign exclude each other')
+            _chk(relu_affine[0], (g.Cin,), name='relu_scale')
+            _chk(relu_affine[1], (g.Cin,), name='relu_shift')
         fuse = BnStatFuse(y.data_ptr(), mask.data_ptr() if mask is not None else None, mean.data_ptr(), invstd.data_ptr(),
-                          partial.data_ptr())
+                          partial.data_ptr(), relu_affine[0].data_ptr() if relu_affine is not None else None,
+                          relu_affine[1].data_ptr() if relu_affine is not None else None)
     ws = _conv_ws(g, 1, dy.device, ws_tag)
     if use_pl:
         _, planes_d = weight_planes(w, g)
@@ -338,7 +366,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
 
 
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, dw: Optional[torch.Tensor] = None,
-               beta: float = 0.0, ws_tag: str = 'wgrad', x3: Optional[bool] = None) -> torch.Tensor:
+               beta: float = 0.0, ws_tag: str = 'wgrad', x3: Optional[bool] = None, pre_bn=None) -> torch.Tensor:
     """dw = beta * dw + dy^T (*) x in one call (split-K main kernel + fixed-order reduction)."""
     _chk_conv(dy, (g.N, g.Ho, g.Wo, g.Cout), g, 'dy')
     _chk_conv(x, (_in_frames(g), g.H, g.W, g.Cin), g, 'x')
@@ -347,9 +375,11 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, dw: Optional[torc
         beta = 0.0
     _chk(dw, (g.Cout, _taps_r(g), g.S, g.Cin), name='dw')
     if WGRAD_X3 if x3 is None else x3:      # the bf16-piece main kernel only exists in the partial + reduce form
-        slab, _ = conv_wgrad_partial(dy, x, g, x3=True, dw=dw)
+        slab, _ = conv_wgrad_partial(dy, x, g, x3=True, dw=dw, pre_bn=pre_bn)
         wgrad_reduce_batched([(slab, dw)], beta=beta)
         return dw
+    if pre_bn is not None:
+        raise ValueError('conv_wgrad: pre_bn needs the bf16-piece plane kernel')
     ws = _conv_ws(g, 2, dy.device, ws_tag)
     check(lib().bdv_conv_wgrad(_p(dy), _p(x), _p(dw), float(beta), ctypes.byref(g), _p(ws), ws.numel(), _stream()),
           'bdv_conv_wgrad')
@@ -438,15 +468,21 @@ def bn_apply(y, scale, shift, res=None, relu=True, out=None, want_mask=False, re
 
 
 def bn_backward(dout, relu_mask, y, gamma, save_mean, save_invstd, relu, dgamma=None, dbeta=None, beta_acc=0.0, dy=None,
-                stat_partial=None):
-    """Returns (dy, dgamma, dbeta).  ``relu_mask`` is the bit mask from ``bn_apply(want_mask=True)`` (needed when relu).
+                stat_partial=None, relu_affine=None):
+    """Returns (dy, dgamma, dbeta).  ``relu_mask`` is the bit mask from ``bn_apply(want_mask=True)`` (needed when relu), or None
+    with ``relu_affine = (scale, shift)``: the sign is then derived from y (a unit whose apply pass never ran).
     ``stat_partial``: the ``(2, rows, C)`` tile sums from ``conv_dgrad(bn_stats=...)``; the statistics pass is skipped."""
     C = y.shape[-1]
     M = y.numel() // C
     _chk(dout, tuple(y.shape), name='dout')
     _chk(y, name='y')
-    if relu:
+    if relu and relu_affine is None:
         _chk(relu_mask, (y.numel() // 32,), dtype=torch.int32, name='relu_mask')
+    if relu_affine is not None:
+        if not relu or relu_mask is not None:
+            raise ValueError('bn_backward: relu_affine goes with relu=True and relu_mask=None')
+        _chk(relu_affine[0], (C,), name='relu_scale')
+        _chk(relu_affine[1], (C,), name='relu_shift')
     for t, n in ((gamma, 'gamma'), (save_mean, 'save_mean'), (save_invstd, 'save_invstd')):
         _chk(t, (C,), name=n)
     if dgamma is None:
@@ -466,7 +502,8 @@ def bn_backward(dout, relu_mask, y, gamma, save_mean, save_invstd, relu, dgamma=
     ws = _bn_ws(M, C, y.device)
     check(lib().bdv_bn_backward(_p(dout), _p(relu_mask if relu else None), _p(y), _p(gamma), _p(save_mean), _p(save_invstd),
                                 _p(d), _p(dgamma), _p(dbeta), float(beta_acc), M, C, int(bool(relu)), _p(stat_partial), srows,
-                                _p(ws), ws.numel(), _stream()), 'bdv_bn_backward')
+                                _p(relu_affine[0] if relu_affine is not None else None),
+                                _p(relu_affine[1] if relu_affine is not None else None), _p(ws), ws.numel(), _stream()), 'bdv_bn_backward')
     return d, dgamma, dbeta
 
 
@@ -645,20 +682,26 @@ WGRAD_X3 = _x3_default('BDVCIL_WGRAD_X3')
 
 
 def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, x3: Optional[bool] = None,
-                       dw: Optional[torch.Tensor] = None):
+                       dw: Optional[torch.Tensor] = None, pre_bn=None):
     """Split-K partial products of a weight gradient -> (slab (splits, Cout, R, S, Cin), empty dw); reduce them later with
     ``wgrad_reduce_batched`` (the slab must stay alive until then)."""
     _chk_conv(dy, (g.N, g.Ho, g.Wo, g.Cout), g, 'dy')
     _chk_conv(x, (_in_frames(g), g.H, g.W, g.Cin), g, 'x')
     use_x3 = WGRAD_X3 if x3 is None else x3
     use_pl = use_x3 and USE_PL_WGRAD
+    if pre_bn is not None:      # x = the producer's raw conv output; its BatchNorm + ReLU is applied in the loader
+        if not (use_pl and lib().bdv_conv_wgrad_pre_ok(ctypes.byref(g))):
+            raise ValueError('conv_wgrad_partial: pre_bn needs the bf16-piece plane kernel for this geometry')
+        _chk(pre_bn[0], (g.Cin,), name='pre_scale')
+        _chk(pre_bn[1], (g.Cin,), name='pre_shift')
     splits = (lib().bdv_conv_wgrad_pl_splits if use_pl else lib().bdv_conv_wgrad_splits)(ctypes.byref(g))
     if splits <= 0:
         check(-1, 'bdv_conv_wgrad_splits')
     slab = torch.empty((splits, g.Cout, _taps_r(g), g.S, g.Cin), dtype=torch.float32, device=dy.device)
     fn = lib().bdv_conv_wgrad_partial_pl if use_pl else lib().bdv_conv_wgrad_partial_x3 if use_x3 else lib().bdv_conv_wgrad_partial
     if use_pl:
-        check(fn(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, PIECES, _stream()), 'bdv_conv_wgrad_partial_pl')
+        check(fn(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, PIECES, _p(pre_bn[0] if pre_bn is not None else None),
+                 _p(pre_bn[1] if pre_bn is not None else None), _stream()), 'bdv_conv_wgrad_partial_pl')
     else:
         check(fn(_p(dy), _p(x), ctypes.byref(g), _p(slab), slab.numel() * 4, _stream()), 'bdv_conv_wgrad_partial')
     if dw is None:

@@ -77,7 +77,7 @@ class ConvTimer:
                 x3 = kw.get('x3')
                 x3 = getattr(K, flag) if x3 is None else x3
                 cin = 3 if g.Cin == 4 else g.Cin
-                flops = 2.0 * g.N * g.Ho * g.Wo * g.Cout * g.R * g.S * cin
+                flops = 2.0 * g.N * g.Ho * g.Wo * g.Cout * g.R * g.S * max(g.Rt, 1) * cin
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 out = fn(*a, **kw)

@@ -101,10 +101,12 @@ int bdv_conv_fprop_x3(const float* x, const float* w, float* y, const bdv_conv_g
  * (bdv_conv_dgrad_stat_rows / bdv_conv_dgrad_pl_stat_rows give the total) and is zeroed by the call. */
 typedef struct bdv_bn_stat_fuse {
   const float* y;            /* [N,H,W,Cin] conv output of the previous unit */
-  const uint32_t* relu_mask; /* 1 bit per element of dx, or NULL (no ReLU) */
+  const uint32_t* relu_mask; /* 1 bit per element of dx, or NULL (no ReLU, or the sign is derived: relu_scale) */
   const float* mean;         /* [Cin] saved batch mean */
   const float* invstd;       /* [Cin] */
   float* partial;            /* float[2][rows][Cin] */
+  const float* relu_scale;   /* optional [Cin] pair with relu_mask == NULL: the unit's ReLU sign is y * relu_scale + relu_shift > 0 */
+  const float* relu_shift;   /* (units whose activation and mask were never written: bdv_conv_fprop_pl(pre_scale)) */
 } bdv_bn_stat_fuse;
 int bdv_conv_dgrad_stat_rows(const bdv_conv_geom* g);
 
@@ -153,9 +155,17 @@ int bdv_conv_uses_planes(const bdv_conv_geom* g, int kind, int pieces);
 int bdv_conv_kernel_name(const bdv_conv_geom* g, int kind, int arith, char* out, size_t n);
 int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* g, int pieces);
 int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* g, int pieces);
+/* pre_scale / pre_shift (optional, [Cin] each): x is then the RAW output of the producing conv and the producer's train-mode
+ * BatchNorm + ReLU, a = max(x * pre_scale[ci] + pre_shift[ci], 0), is applied in the loader (the same fused multiply-add as
+ * bdv_bn_apply, bit-identical activations; halo / ragged lanes stay zero): the apply pass between the two convs, the activation
+ * tensor and its ReLU mask are not needed for this consumer (UPSTREAM ConvModule conv -> bn -> relu chains inside Bottleneck /
+ * BasicBlock).  Needs pieces = 3, no temporal shift, and bdv_conv_fprop_pre_ok(g); the statistics partial then has
+ * bdv_conv_fprop_pre_stat_rows(g) rows. */
 int bdv_conv_fprop_pl(const float* x, const float* w, const void* planes_fprop, float* y, const bdv_conv_geom* g,
                       float* bn_partial, const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, int pieces,
-                      void* stream);
+                      const float* pre_scale, const float* pre_shift, void* stream);
+int bdv_conv_fprop_pre_ok(const bdv_conv_geom* g);
+int bdv_conv_fprop_pre_stat_rows(const bdv_conv_geom* g);
 int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* planes_dgrad, float* dx, const float* add_src,
                       const uint32_t* add_mask_src, const bdv_conv_geom* g, const bdv_bn_stat_fuse* bn_stat, void* workspace,
                       size_t workspace_bytes, int pieces, void* stream);
@@ -180,8 +190,11 @@ int bdv_wgrad_reduce_batched(const float* const* slabs, float* const* dws, const
  * both operand tiles split into bf16 pieces in the loader and read from LDS with ds_read_b64_tr_b16.  The slab holds
  * bdv_conv_wgrad_pl_splits(g) partial products of dw's size; reduce with bdv_wgrad_reduce_batched. */
 int bdv_conv_wgrad_pl_splits(const bdv_conv_geom* g);
+/* pre_scale / pre_shift as for bdv_conv_fprop_pl: x is the producer's raw conv output and the activation
+ * max(x * pre_scale[ci] + pre_shift[ci], 0) is formed in the loader (needs bdv_conv_wgrad_pre_ok(g)). */
 int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const bdv_conv_geom* g, void* slab, size_t slab_bytes,
-                              int pieces, void* stream);
+                              int pieces, const float* pre_scale, const float* pre_shift, void* stream);
+int bdv_conv_wgrad_pre_ok(const bdv_conv_geom* g);
 /* EXPERIMENTAL counterpart of bdv_conv_fprop_x3 for the weight gradient's main kernel (128x128 tiles, i.e. Cout and Cin
  * multiples of 128; other shapes run the fp32-MFMA kernels).  Same slab layout and split count as bdv_conv_wgrad_partial. */
 int bdv_conv_wgrad_partial_x3(const float* dy, const float* x, const bdv_conv_geom* g, void* slab, size_t slab_bytes,
@@ -217,10 +230,12 @@ int bdv_bn_apply(const float* y, const float* scale, const float* shift, const f
  * beta_acc*old + new.  The residual-path gradient is g itself; consumers re-derive it from
  * (dout, relu_mask) -- see bdv_conv_dgrad(add_src, add_mask_src) and bdv_relu_bwd. */
 /* stat_partial (optional): float[2][stat_rows][C] written by bdv_conv_dgrad(bn_stat); the statistics pass is skipped. */
+/* relu_scale / relu_shift (optional [C] pair, with relu != 0 and relu_mask == NULL): the ReLU sign is derived from y as
+ * y * relu_scale + relu_shift > 0, the forward's own expression, for units whose mask was never written. */
 int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, const float* y, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dy, float* dgamma,
                     float* dbeta, float beta_acc, int64_t M, int C, int relu, const float* stat_partial, int stat_rows,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    const float* relu_scale, const float* relu_shift, void* workspace, size_t workspace_bytes, void* stream);
 /* g = dout * relu_mask (+ add) : masked gradient for an identity path that has no conv behind it */
 int bdv_relu_bwd(const float* dout, const uint32_t* relu_mask, const float* add, float* g, int64_t numel, void* stream);
 /* out = a + b (gradient junctions) */

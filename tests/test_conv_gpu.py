@@ -330,6 +330,59 @@ def test_weight_plane_cache_follows_the_weights(dev):
     assert key not in K._PLANES                                               # the planes die with the weight
 
 
+PRE_CASES = [
+    (16, 14, 14, 128, 256, 1, 1, 0),      # conv3-like 1x1
+    (8, 9, 9, 64, 512, 1, 1, 0),          # ragged M
+    (64, 14, 14, 256, 1024, 1, 1, 0),     # K-split remainder tiles
+    (8, 12, 12, 64, 64, 3, 1, 1),         # conv2 of layer 1: 3x3 halo, 64 columns
+    (4, 9, 11, 128, 128, 3, 1, 1),        # 3x3, odd sizes, 128 columns (tile the planner would not pick without pre_bn)
+    (8, 12, 12, 256, 256, 3, 2, 1),       # stride-2 conv2 of a first block
+    (16, 7, 7, 512, 512, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', PRE_CASES)
+def test_producer_batchnorm_in_the_consumers_loaders(case, dev):
+    """conv_fprop / conv_wgrad with pre_bn=(scale, shift) on the RAW output of the producing conv == bdv_bn_apply followed by the
+    same conv on the activation, bit for bit (the loaders use bn_apply's fused multiply-add; halo and ragged lanes stay zero);
+    and the backward kernels that derive the ReLU sign from the conv output == the ones that read the 1-bit mask."""
+    from bdvcil_amd import kernels as K
+    N, H, W, Cin, Cout, R, st, pad = case
+    gen = torch.Generator().manual_seed(N + Cin + R)
+    g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad)
+    assert K.fprop_pre_ok(g)
+    y_prev = torch.randn(N, H, W, Cin, generator=gen).to(dev)            # raw conv output of the producing unit
+    w = (torch.randn(Cout, R, R, Cin, generator=gen) * 0.05).to(dev)
+    gamma = (torch.rand(Cin, generator=gen) + 0.5).to(dev)
+    beta = (torch.randn(Cin, generator=gen) * 0.2).to(dev)
+    mean, invstd, scale, shift = K.bn_train_stats(y_prev, gamma, beta, 1e-5, 0.1, None, None)
+    act, mask = K.bn_apply(y_prev, scale, shift, None, True, want_mask=True)
+    # forward, with the fused statistics
+    ref, pref = K.conv_fprop(act, w, g, bn_stats=True)
+    got, pgot = K.conv_fprop(y_prev, w, g, bn_stats=True, pre_bn=(scale, shift))
+    cpu = F.conv2d(torch.relu(y_prev.cpu() * scale.cpu() + shift.cpu()).permute(0, 3, 1, 2), w.cpu().permute(0, 3, 1, 2), stride=st, padding=pad)
+    _close(got.cpu().permute(0, 3, 1, 2), cpu)
+    _close(got.cpu(), ref.cpu(), tol=2e-6)          # (another tile than the planner's choice may sum in another order)
+    _close(pgot.double().sum(1).cpu(), pref.double().sum(1).cpu(), tol=1e-5)
+    # weight gradient: the activation operand formed in the loader
+    dy = torch.randn(N, g.Ho, g.Wo, Cout, generator=gen).to(dev)
+    assert torch.equal(K.conv_wgrad(dy, y_prev, g, pre_bn=(scale, shift)), K.conv_wgrad(dy, act, g))
+    # the gradient entering the producer's BatchNorm: statistics in the dgrad epilogue and the BatchNorm backward, sign derived from y
+    if st == 1 or R > 1:
+        dx_m, part_m = K.conv_dgrad(dy, w, g, bn_stats=(y_prev, mask, mean, invstd))
+        dx_d, part_d = K.conv_dgrad(dy, w, g, bn_stats=(y_prev, None, mean, invstd, (scale, shift)))
+        assert torch.equal(dx_m, dx_d) and torch.equal(part_m, part_d)
+        a = K.bn_backward(dx_m, mask, y_prev, gamma, mean, invstd, True, stat_partial=part_m)
+        b = K.bn_backward(dx_d, None, y_prev, gamma, mean, invstd, True, stat_partial=part_d, relu_affine=(scale, shift))
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    dx = K.conv_dgrad(dy, w, g)
+    a = K.bn_backward(dx, mask, y_prev, gamma, mean, invstd, True)            # standalone statistics pass
+    b = K.bn_backward(dx, None, y_prev, gamma, mean, invstd, True, relu_affine=(scale, shift))
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
 PL_CASES = [
     (16, 14, 14, 128, 256, 1, 1, 0, 8, 16),     # 1x1 + shift, Cout 256
     (8, 9, 9, 128, 256, 3, 1, 1, 1, 0),         # 3x3, odd size, ragged M (648 rows)

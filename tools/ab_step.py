@@ -29,8 +29,8 @@ batch = dict(imgs=torch.randn(32, 8, 3, 224, 224, generator=g).to(dev), label=to
 VARIANTS = {
     'one stream': dict(side=False, ds=False, prio=False, batch=True),
     'side streams (default)': dict(side=True, ds=True, prio=False, batch=True),
-    'side streams, plain BN loads': dict(side=True, ds=True, prio=False, batch=True, nt=0),
-    'side streams, BN loads non-temporal except the residual': dict(side=True, ds=True, prio=False, batch=True, nt=1),
+    'side streams, BDVCIL_PRE_BN=fwd (consumer conv applies the BatchNorm; apply pass for backward on the side stream)': dict(side=True, ds=True, prio=False, batch=True, pre='fwd'),
+    'side streams, BDVCIL_PRE_BN=1 (no activation / mask; recomputed for wgrad)': dict(side=True, ds=True, prio=False, batch=True, pre=True),
 }
 
 
@@ -40,6 +40,9 @@ def run(cfg, n):
     CS._MAIN_HIGH_PRIORITY = cfg['prio']
     Fn.BATCH_WGRAD_REDUCE = cfg['batch']
     os.environ['BDVCIL_BN_NT'] = str(cfg.get('nt', 2))
+    Fn.PRE_BN = cfg.get('pre', False) is True
+    Fn.PRE_BN_FWD = cfg.get('pre', False) == 'fwd'
+    Fn.PRE_BN_WGRAD = cfg.get('wg', 'recompute')
     for _ in range(2):
         engine.step(batch)
     torch.cuda.synchronize()

@@ -1,9 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_conv_gpu.py tests/test_model_gpu.py tests/test_i3d_gpu.py -m gpu -q -x > gpurun_out/pytest_ops.log 2>&1
-echo "[pytest] rc=$?"; tail -n 3 gpurun_out/pytest_ops.log
-OLD=$GRAFT_REPO_ROOT/background-debiased-video-cil_amd/csrc/libbdvcil_hip_old.so
-for i in 1 2; do
-timeout -k 10 300 python bench.py --steps 12 --warmup 4 --no-cpu-baseline > gpurun_out/bench_new$i.log 2>&1
-echo "[bench_new$i] rc=$?"; tail -n 1 gpurun_out/bench_new$i.log | cut -c58-110
-done
+timeout -k 10 900 python -m pytest tests/test_model_gpu.py -m gpu -q -x -k "bit_identical or train_step" > gpurun_out/pytest_model.log 2>&1
+echo "[pytest model] rc=$?"; tail -n 4 gpurun_out/pytest_model.log | cut -c1-300
+timeout -k 10 400 python tools/ab_step.py 4 10 > gpurun_out/ab_step.log 2>&1; tail -5 gpurun_out/ab_step.log
