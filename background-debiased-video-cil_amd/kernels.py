@@ -244,9 +244,14 @@ def conv_kernel_name(g: ConvGeom, kind: str, x3: Optional[bool] = None) -> str:
     return buf.value.decode()
 
 
+PRE_BN_1X1_ONLY = _os.environ.get('BDVCIL_PRE_BN_3X3', '0') == '0'
+
+
 def fprop_pre_ok(g: ConvGeom) -> bool:
     """True when ``conv_fprop(pre_bn=...)`` and ``conv_wgrad*(pre_bn=...)`` can apply the producer's BatchNorm + ReLU in their
     loaders for this geometry (bf16-piece arithmetic with the plane kernels; no temporal shift)."""
+    if PRE_BN_1X1_ONLY and (g.R != 1 or g.S != 1):   # a 3x3 consumer re-applies the BatchNorm once per filter tap: measured slower
+        return False
     return bool(PIECES == 3 and FPROP_X3 and WGRAD_X3 and DGRAD_X3 and USE_PL and USE_PL_WGRAD and g.fold == 0 and g.Rt <= 1
                 and not getattr(g, 'frames_view', False)
                 and lib().bdv_conv_fprop_pre_ok(ctypes.byref(g)) and lib().bdv_conv_wgrad_pre_ok(ctypes.byref(g)))

@@ -12,6 +12,7 @@ import torch
 import bdvcil_amd as bd
 from bdvcil_amd import cil_step as CS
 from bdvcil_amd import functional as Fn
+from bdvcil_amd import kernels as K
 from bench import model_cfg
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
@@ -27,10 +28,11 @@ g = torch.Generator().manual_seed(1000)
 batch = dict(imgs=torch.randn(32, 8, 3, 224, 224, generator=g).to(dev), label=torch.randint(0, 101, (32, 1), generator=g).to(dev))
 
 VARIANTS = {
-    'one stream': dict(side=False, ds=False, prio=False, batch=True),
     'side streams (default)': dict(side=True, ds=True, prio=False, batch=True),
-    'side streams, BDVCIL_PRE_BN=fwd (consumer conv applies the BatchNorm; apply pass for backward on the side stream)': dict(side=True, ds=True, prio=False, batch=True, pre='fwd'),
-    'side streams, BDVCIL_PRE_BN=1 (no activation / mask; recomputed for wgrad)': dict(side=True, ds=True, prio=False, batch=True, pre=True),
+    'BDVCIL_PRE_BN=fwd, 1x1 consumers only': dict(side=True, ds=True, prio=False, batch=True, pre='fwd'),
+    'BDVCIL_PRE_BN=1, 1x1 consumers only': dict(side=True, ds=True, prio=False, batch=True, pre=True),
+    'BDVCIL_PRE_BN=fwd, 3x3 consumers too': dict(side=True, ds=True, prio=False, batch=True, pre='fwd', k3=True),
+    'BDVCIL_PRE_BN=1, 3x3 consumers too': dict(side=True, ds=True, prio=False, batch=True, pre=True, k3=True),
 }
 
 
@@ -42,6 +44,7 @@ def run(cfg, n):
     os.environ['BDVCIL_BN_NT'] = str(cfg.get('nt', 2))
     Fn.PRE_BN = cfg.get('pre', False) is True
     Fn.PRE_BN_FWD = cfg.get('pre', False) == 'fwd'
+    K.PRE_BN_1X1_ONLY = not cfg.get('k3', False)
     Fn.PRE_BN_WGRAD = cfg.get('wg', 'recompute')
     for _ in range(2):
         engine.step(batch)
