@@ -342,7 +342,7 @@ PRE_CASES = [
 
 
 @pytest.mark.parametrize('case', PRE_CASES)
-def test_producer_batchnorm_in_the_consumers_loaders(case, dev):
+def test_producer_batchnorm_in_the_consumers_loaders(case, dev, monkeypatch):
     """conv_fprop / conv_wgrad with pre_bn=(scale, shift) on the RAW output of the producing conv == bdv_bn_apply followed by the
     same conv on the activation, bit for bit (the loaders use bn_apply's fused multiply-add; halo and ragged lanes stay zero);
     and the backward kernels that derive the ReLU sign from the conv output == the ones that read the 1-bit mask."""
@@ -350,6 +350,8 @@ def test_producer_batchnorm_in_the_consumers_loaders(case, dev):
     N, H, W, Cin, Cout, R, st, pad = case
     gen = torch.Generator().manual_seed(N + Cin + R)
     g = K.make_geom(N, H, W, Cin, Cout, R, R, st, pad)
+    assert K.fprop_pre_ok(g) == (R == 1)            # the model only lets 1x1 consumers take part unless BDVCIL_PRE_BN_3X3=1
+    monkeypatch.setattr(K, 'PRE_BN_1X1_ONLY', False)
     assert K.fprop_pre_ok(g)
     y_prev = torch.randn(N, H, W, Cin, generator=gen).to(dev)            # raw conv output of the producing unit
     w = (torch.randn(Cout, R, R, Cin, generator=gen) * 0.05).to(dev)

@@ -169,12 +169,14 @@ def _rel_l2(a, b):
 
 
 @pytest.mark.parametrize('depth', [18, 50])
-def test_train_step_is_bit_identical_with_and_without_the_apply_passes(depth, dev):
+def test_train_step_is_bit_identical_with_and_without_the_apply_passes(depth, dev, monkeypatch):
     """BDVCIL_PRE_BN=1 (off by default: measured 0.6 ms per step slower; it saves the memory of the
     activations between conv1 / conv2 / conv3): the BatchNorm + ReLU of conv1 / conv2 applied in the loaders of the conv that
     consumes them, their activation and mask never written, ReLU signs derived from the conv output in the backward kernels.
     Both weight-gradient forms (activation recomputed / BatchNorm in the loader).  R18: not a bit of the training step changes."""
     from bdvcil_amd import functional as Fn
+    from bdvcil_amd import kernels as KK
+    monkeypatch.setattr(KK, 'PRE_BN_1X1_ONLY', False)       # 3x3 consumers too (R18 has no others)
     ref, mod, _ = _pair(depth, 'LocalSimilarityClassifier', 'LSCLoss', K=11, dev=dev)
     state = copy.deepcopy(mod.state_dict())
     imgs, labels = _clips(2, 8, 64, 11, seed=3)
