@@ -78,11 +78,20 @@ class ConvTimer:
                 x3 = getattr(K, flag) if x3 is None else x3
                 cin = 3 if g.Cin == 4 else g.Cin
                 flops = 2.0 * g.N * g.Ho * g.Wo * g.Cout * g.R * g.S * max(g.Rt, 1) * cin
+                # algorithmic bytes of the call: every operand and result tensor once (fp32), plus what the fused epilogues stream
+                n_in = g.N * max(g.st_t, 1) * g.H * g.W * g.Cin if g.Rt > 1 else g.N * g.H * g.W * g.Cin
+                n_out = g.N * g.Ho * g.Wo * g.Cout
+                n_w = g.Cout * g.R * g.S * max(g.Rt, 1) * g.Cin
+                nbytes = 4.0 * (n_in + n_out + n_w)
+                if kind == 'dgrad':
+                    nbytes += 4.0 * n_in * ((kw.get('add_src') is not None) + (kw.get('bn_stats') is not None))
+                if kind == 'fprop' and kw.get('affine') is not None and kw['affine'][2] is not None:
+                    nbytes += 4.0 * n_out
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 out = fn(*a, **kw)
                 e1.record()
-                timer.records.append((kernel_tag(kind, g, x3), flops, e0, e1))
+                timer.records.append((kernel_tag(kind, g, x3), flops, e0, e1, nbytes))
                 return out
             return timed
 
@@ -94,7 +103,7 @@ class ConvTimer:
                 e0.record()
                 out = fn(*a, **kw)
                 e1.record()
-                timer.records.append(('wgrad_reduce_batched_kernel', 0.0, e0, e1))
+                timer.records.append(('wgrad_reduce_batched_kernel', 0.0, e0, e1, 0.0))
                 return out
             return timed
 
@@ -114,12 +123,13 @@ class ConvTimer:
 
     def summary(self):
         by = {}
-        for tag, flops, e0, e1 in self.records:
+        for tag, flops, e0, e1, nbytes in self.records:
             ms = e0.elapsed_time(e1)
-            d = by.setdefault(tag, dict(launches=0, ms=0.0, flops=0.0))
+            d = by.setdefault(tag, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d['launches'] += 1
             d['ms'] += ms
             d['flops'] += flops
+            d['bytes'] += nbytes
         return by
 
 
@@ -438,6 +448,7 @@ def main():
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                 'rocprof_avg_us': rocprof_avg_us(dom),
                 'algorithmic_gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 2),
+                'algorithmic_bytes_per_launch': int(d['bytes'] / d['launches']),      # operands + results once (+ fused epilogue tensors): compare with `traffic`
                 'all_conv_kernels': {k: {'launches_per_step': v['launches'] // timed_steps, 'ms_per_step': round(v['ms'] / timed_steps, 3),
                                          'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['flops'] else None,
                                          'rocprof_avg_us': rocprof_avg_us(k)} for k, v in sorted(by.items())},
