@@ -525,6 +525,21 @@ class ResBlockFn(torch.autograd.Function):
         return (dx, None, None, *grads)
 
 
+class StageLink:
+    """Side channel between two consecutive stages run as ResStageFn nodes, valid only while the first stage's output has the
+    second stage as its ONLY consumer (no hook on the stage module): the producer leaves the BatchNorm-backward operands of its
+    last unit (``stats``), the consumer's backward -- whose first conv1 dgrad writes the gradient w.r.t. that output -- takes their
+    statistics in its epilogue and leaves the tile sums (``partial``) for the producer's backward, which runs after it."""
+    __slots__ = ('stats', 'partial')
+
+    def __init__(self):
+        self.stats = None
+        self.partial = None
+
+
+CROSS_STAGE_STATS = _os.environ.get('BDVCIL_CROSS_STAGE_STATS', '1') != '0'
+
+
 class ResStageFn(torch.autograd.Function):
     """A whole stage (UPSTREAM ResNet.layerN = a sequence of residual blocks) as ONE autograd node.  The tensors
     between its blocks are then private to this node (exactly one producer and one consumer), which is what allows
@@ -533,7 +548,7 @@ class ResStageFn(torch.autograd.Function):
     (widest) tensor.  Arithmetic per block is that of ResBlockFn."""
 
     @staticmethod
-    def forward(ctx, x, blocks, training, *params):
+    def forward(ctx, x, blocks, training, in_link, out_link, *params):
         save = training and any(ctx.needs_input_grad)
         cur, off = x, 0
         all_saved, meta = [], []
@@ -544,8 +559,16 @@ class ResStageFn(torch.autograd.Function):
             all_saved += saved
             off += npar
             cur = out
+        # the previous stage's last unit: operands for the statistics this stage's first conv1 dgrad can take for it
+        in_stats = in_link.stats if (save and in_link is not None and CROSS_STAGE_STATS and FUSE_BN_STATS) else None
+        if in_stats is not None and not (meta[0][2][0].stride == 1 and ctx.needs_input_grad[0]):
+            in_stats = None
         if save:
-            ctx.save_for_backward(*all_saved, *params)
+            ctx.save_for_backward(*all_saved, *params, *(in_stats or ()))
+            if out_link is not None:
+                out_link.stats = _block_out_stats(all_saved[len(all_saved) - meta[-1][0]:], meta[-1][3])
+        ctx.in_link = in_link if in_stats is not None else None
+        ctx.out_link = out_link if save else None
         ctx.meta = meta
         ctx.bn_training = training
         return cur
@@ -557,8 +580,11 @@ class ResStageFn(torch.autograd.Function):
         t = ctx.saved_tensors
         meta = ctx.meta
         n_saved_total = sum(m[0] for m in meta)
+        in_stats = None
+        if ctx.in_link is not None:
+            t, in_stats = t[:-4], tuple(t[-4:])
         saved_all, params_all = t[:n_saved_total], t[n_saved_total:]
-        need = ctx.needs_input_grad      # (x, blocks, training, *params)
+        need = ctx.needs_input_grad      # (x, blocks, training, in_link, out_link, *params)
         s_off = [0]
         p_off = [0]
         for m in meta:
@@ -566,20 +592,24 @@ class ResStageFn(torch.autograd.Function):
             p_off.append(p_off[-1] + m[1])
         grads_all: List[Optional[torch.Tensor]] = [None] * len(params_all)
         d, part = dout, None
+        if ctx.out_link is not None:     # the next stage's backward ran before this one and took the statistics of `dout`
+            part, ctx.out_link.partial = ctx.out_link.partial, None
         with wgrad_batch():              # one split-K reduction launch for the weight gradients of the whole stage
             for k in range(len(meta) - 1, -1, -1):
                 n_saved, npar, geoms, n_main, has_down = meta[k]
                 saved = saved_all[s_off[k]:s_off[k + 1]]
                 params = params_all[p_off[k]:p_off[k + 1]]
-                prev_stats = None
+                prev_stats = in_stats if k == 0 else None
                 if k > 0:
                     pm = meta[k - 1]
                     prev_stats = _block_out_stats(saved_all[s_off[k - 1]:s_off[k]], pm[3])
                 need_dx = need[0] or k > 0
-                d, grads, part = _block_backward(saved, params, geoms, n_main, has_down, d, need[3 + p_off[k]:3 + p_off[k + 1]],
+                d, grads, part = _block_backward(saved, params, geoms, n_main, has_down, d, need[5 + p_off[k]:5 + p_off[k + 1]],
                                                  need_dx, out_stat_partial=part, prev_stats=prev_stats)
                 grads_all[p_off[k]:p_off[k + 1]] = grads
-        return (d, None, None, *grads_all)
+        if ctx.in_link is not None:
+            ctx.in_link.partial = part   # tile sums of the statistics of `d` against the previous stage's last unit
+        return (d, None, None, None, None, *grads_all)
 
 
 class AvgPoolFn(torch.autograd.Function):

@@ -169,7 +169,10 @@ class ResStage(nn.Sequential):
         flags = {b.unit_bns[0].training for b in blocks}
         if len(flags) != 1:
             return super().forward(x)
-        out = Fn.ResStageFn.apply(xh, blocks, flags.pop(), *params)
+        # links to the neighbouring stages (set by the backbone's forward for this call only; see Fn.StageLink)
+        in_link, out_link = getattr(self, '_in_link', None), getattr(self, '_out_link', None)
+        self._in_link = self._out_link = None
+        out = Fn.ResStageFn.apply(xh, blocks, flags.pop(), in_link, out_link, *params)
         return Fn.nhwc_to_nchw_view(out)
 
 
@@ -309,8 +312,20 @@ class ResNetTSM(nn.Module):
             torch._foreach_add_([b.num_batches_tracked for b in self._bn_modules() if b.training], 1)
         p = Fn.StemFn.apply(x4, stem.conv.weight, stem.bn.weight, stem.bn.bias, stem.bn, training)
         out = Fn.nhwc_to_nchw_view(p)
-        for name in self.res_layers:
-            out = getattr(self, name)(out)
+        link = None
+        for i, name in enumerate(self.res_layers):
+            stage = getattr(self, name)
+            if isinstance(stage, ResStage):
+                stage._in_link = link
+                # this stage's output is private to the next stage unless something hooks the stage module (OutputHook for the
+                # feature-KD terms does): only then may the next stage's backward take BatchNorm statistics for this one
+                private = (i + 1 < len(self.res_layers) and not stage._forward_hooks and not stage._backward_hooks
+                           and not torch.nn.modules.module._global_forward_hooks)
+                link = Fn.StageLink() if (training and private) else None
+                stage._out_link = link
+            else:
+                link = None
+            out = stage(out)
         return out
 
     def train(self, mode=True):

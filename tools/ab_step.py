@@ -28,11 +28,10 @@ g = torch.Generator().manual_seed(1000)
 batch = dict(imgs=torch.randn(32, 8, 3, 224, 224, generator=g).to(dev), label=torch.randint(0, 101, (32, 1), generator=g).to(dev))
 
 VARIANTS = {
+    'one stream': dict(side=False, ds=False, prio=False, batch=True),
     'side streams (default)': dict(side=True, ds=True, prio=False, batch=True),
-    'BDVCIL_PRE_BN=fwd, 1x1 consumers only': dict(side=True, ds=True, prio=False, batch=True, pre='fwd'),
-    'BDVCIL_PRE_BN=1, 1x1 consumers only': dict(side=True, ds=True, prio=False, batch=True, pre=True),
-    'BDVCIL_PRE_BN=fwd, 3x3 consumers too': dict(side=True, ds=True, prio=False, batch=True, pre='fwd', k3=True),
-    'BDVCIL_PRE_BN=1, 3x3 consumers too': dict(side=True, ds=True, prio=False, batch=True, pre=True, k3=True),
+    'side streams, no BatchNorm statistics across stage boundaries': dict(side=True, ds=True, prio=False, batch=True, xs=False),
+    'side streams, BDVCIL_PRE_BN=1 (1x1 consumers)': dict(side=True, ds=True, prio=False, batch=True, pre=True),
 }
 
 
@@ -44,6 +43,7 @@ def run(cfg, n):
     os.environ['BDVCIL_BN_NT'] = str(cfg.get('nt', 2))
     Fn.PRE_BN = cfg.get('pre', False) is True
     Fn.PRE_BN_FWD = cfg.get('pre', False) == 'fwd'
+    Fn.CROSS_STAGE_STATS = cfg.get('xs', True)
     K.PRE_BN_1X1_ONLY = not cfg.get('k3', False)
     Fn.PRE_BN_WGRAD = cfg.get('wg', 'recompute')
     for _ in range(2):
