@@ -2142,7 +2142,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
 // ---- dgrad ------------------------------------------------------------------------------------
 // dp = the D planes of bdv_conv_split_weights: B rows = input channels ci, contraction over (tap, co) with co contiguous.
 template <int BM, int BN, int WM, int WN, int NBUF, int NP = 3>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_dgrad_pl_kernel(const float* __restrict__ dy,
+__global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : (WM * WN) / 4) void conv_dgrad_pl_kernel(const float* __restrict__ dy,
                                                                                       const unsigned short* __restrict__ dp,
                                                                                       float* __restrict__ dx,
                                                                                       const float* __restrict__ add_src,
@@ -2734,8 +2734,10 @@ struct PlCfg {
   int BM, BN, nbuf;
   double iter_us;  // one 32-deep K-step of a block, measured per-CU rate (tools/ubench/gemm_x3p.hip: ~200 / ~230 TFLOP/s chip-wide)
 };
-constexpr int kNumPlCfg = 4;
-constexpr PlCfg kPlCfg[kNumPlCfg] = {{128, 256, 2, 2.7}, {256, 128, 2, 2.7}, {256, 256, 1, 4.7}, {256, 64, 2, 1.9}};
+constexpr int kNumPlCfg = 5;
+// 4 = 64 x 128, four waves, FOUR workgroups per CU: for dgrads whose epilogue streams as many bytes as their K loop takes MFMA time
+// (a block's conv1), so that one tile's epilogue runs beside other tiles' K loops; dgrad only
+constexpr PlCfg kPlCfg[kNumPlCfg] = {{128, 256, 2, 2.7}, {256, 128, 2, 2.7}, {256, 256, 1, 4.7}, {256, 64, 2, 1.9}, {64, 128, 1, 0.7}};
 
 struct PlPlan {
   int cfg;  // -1: shape not covered by the P kernels
@@ -2793,16 +2795,21 @@ int pl_tile_override() {
 //     and for a block's conv1 (1x1 with the temporal shift): in the training step its epilogue adds the identity-branch gradient
 //     and takes the BatchNorm-backward statistics, i.e. it streams three tensors of the output's size and is HBM-bound; two
 //     workgroups per CU overlap one tile's epilogue with another's K loop and win for >= 512 columns and for 256 columns with
-//     K >= 128.
+//     K >= 128;
+//   * BDVCIL_DGRAD_64X128=1 (off): 64x128 tiles with FOUR workgroups per CU for those conv1 dgrads and the 128-column conv3 dgrads.
+//     Alone they are faster (0.541 against 0.612 ms on 256<-64 @56, 0.225 against 0.263 on 1024<-256 @14, ...: -0.76 ms per step
+//     summed over the sites, profiles/r02_tune_conv_fused.txt); in the whole step, where the weight gradients of the layer above
+//     run beside them on the second stream, three alternating pairs of runs gave 587.9 / 588.1 / 586.4 clips/s with the rule
+//     against 589.9 / 590.9 / 588.1 without (profiles/r02_ab_streams.txt) -- kept as a tested tile, not chosen by default.
 // Returns the tile configuration, or -1 for the kernels that take fp32 weights.  BDVCIL_PL_TILE / bdv_conv_debug_force_tile
 // override the rules wherever the forced tile divides the column count.
 int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride, int pieces = 3, bool shifted = false) {
   const int forced = pl_tile_override();
   if (pieces == 1)  // the single-product arithmetic only exists in the 8-wave kernels
-    return forced >= 0 && forced < kNumPlCfg && ncols % kPlCfg[forced].BN == 0 ? forced
+    return forced >= 0 && forced < kNumPlCfg && ncols % kPlCfg[forced].BN == 0 && (forced != 4 || (dgrad && stride == 1)) ? forced
            : ncols % 256 == 0 ? 0 : ncols % 128 == 0 ? 1 : ncols % 64 == 0 ? 3 : -1;
   if (forced == kNumPlCfg) return -1;  // "none": the kernels of the other family everywhere
-  if (forced >= 0 && ncols % kPlCfg[forced].BN == 0) return forced;
+  if (forced >= 0 && ncols % kPlCfg[forced].BN == 0 && (forced != 4 || (dgrad && stride == 1))) return forced;
   if (ncols % 64 != 0) return -1;
   if (ncols % 128 != 0) return taps > 1 ? 3 : -1;
   if (!dgrad) {
@@ -2810,8 +2817,10 @@ int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride, int pieces = 3,
     if (nk >= 16 || nk <= 2) return 0;
     return -1;
   }
-  if (ncols % 256 != 0) return taps > 1 && stride == 1 ? 1 : -1;
+  static const bool small_tiles = getenv("BDVCIL_DGRAD_64X128") != nullptr && atoi(getenv("BDVCIL_DGRAD_64X128")) != 0;
+  if (ncols % 256 != 0) return taps > 1 && stride == 1 ? 1 : (small_tiles && taps == 1 && stride == 1 && nk >= 16 ? 4 : -1);
   if (stride == 2 && taps > 1) return 0;
+  if (small_tiles && shifted && taps == 1) return 4;
   if (nk <= 8 && ncols >= 1024) return -1;
   if (shifted && taps == 1 && (ncols >= 512 || nk >= 4)) return -1;
   if (ncols == 512 && nk >= 64) return 0;
@@ -2830,7 +2839,7 @@ PlPlan plan_pl(int cfg, int M, int ncols, int nk, size_t ws_bytes, bool ksplit_o
   p.NT = ncols / k.BN;
   p.nk = nk;
   p.seg_bytes = (size_t)k.BM * k.BN * sizeof(float);
-  if (ksplit_ok) {
+  if (ksplit_ok && cfg != 4) {   // (the 64 x 128 tile runs four workgroups per CU: thousands of tiles, no remainder worth splitting)
     p.wk = plan_work_pl(p.MT * p.NT, nk, k.iter_us, p.seg_bytes, ws_bytes, &p.est_us);
   } else {
     p.wk.dp_tiles = p.MT * p.NT;
@@ -3196,7 +3205,7 @@ extern "C" size_t bdv_conv_weight_planes_bytes(const bdv_conv_geom* gg) {
 }
 
 extern "C" int bdv_conv_debug_force_tile(int cfg) {
-  BDV_REQUIRE(cfg >= -1 && cfg <= kNumPlCfg, "bdv_conv_debug_force_tile: cfg %d (-1 automatic, 0 = 128x256, 1 = 256x128, 2 = 256x256, 3 = 256x64, 4 = none)", cfg);
+  BDV_REQUIRE(cfg >= -1 && cfg <= kNumPlCfg, "bdv_conv_debug_force_tile: cfg %d (-1 automatic, 0 = 128x256, 1 = 256x128, 2 = 256x256, 3 = 256x64, 4 = 64x128 (dgrad), 5 = none)", cfg);
   g_pl_tile_forced = cfg;
   return BDV_OK;
 }
@@ -3223,8 +3232,8 @@ extern "C" int bdv_conv_kernel_name(const bdv_conv_geom* gg, int kind, int arith
   } else if (kind == 1) {
     const int cfg = arith ? pl_dgrad_cfg(gg, arith == 2 ? 1 : 3) : -1;
     if (cfg >= 0) {
-      const int wm = cfg == 0 || cfg == 2 ? 2 : 4;
-      snprintf(out, n, "conv_dgrad_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, wm, 8 / wm, kPlCfg[cfg].nbuf, arith == 2 ? 1 : 3);
+      const int wm = cfg == 0 || cfg == 2 || cfg == 4 ? 2 : 4;
+      snprintf(out, n, "conv_dgrad_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, wm, cfg == 4 ? 2 : 8 / wm, kPlCfg[cfg].nbuf, arith == 2 ? 1 : 3);
     } else if (gg->Cin % 128 == 0 && arith) {
       snprintf(out, n, "conv_dgrad_x3_kernel<128, 128, 2, 2, %s>", r1_planes_enabled() ? "true" : "false");
     } else {
@@ -3428,6 +3437,7 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
   if (p.cfg == 0) BDV_DGRAD_PL(128, 256, 2, 4, 2);
   else if (p.cfg == 1) BDV_DGRAD_PL(256, 128, 4, 2, 2);
   else if (p.cfg == 2) BDV_DGRAD_PL(256, 256, 2, 4, 1);
+  else if (p.cfg == 4) BDV_DGRAD_PL(64, 128, 2, 2, 1);
   else BDV_DGRAD_PL(256, 64, 4, 2, 2);
 #undef BDV_DGRAD_PL
   return BDV_OK;
