@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # is then the caller's business
 _OVERRIDE = os.environ.get('BDVCIL_LIB_PATH')
 LIB_PATH = _OVERRIDE or os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _lib = None
 
@@ -23,7 +23,7 @@ _lib = None
 class ConvGeom(Structure):
     """Mirror of ``bdv_conv_geom``."""
     _fields_ = [(n, c_int32) for n in
-                ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'R', 'S', 'stride', 'pad', 'T', 'fold', 'pad_w', 'Rt', 'st_t')]
+                ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'R', 'S', 'stride', 'pad', 'T', 'fold', 'pad_w', 'Rt', 'st_t', 'act_dtype')]
 
     def key(self):
         return tuple(getattr(self, n) for n, _ in self._fields_)
@@ -80,19 +80,19 @@ SIGNATURES = {
     'bdv_bn_train_stats': (c_int, [P, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, c_size_t, P]),
     'bdv_bn_train_finalize': (c_int, [P, c_int, c_int64, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P]),
     'bdv_bn_eval_params': (c_int, [c_int, P, P, P, P, c_float, P, P, P]),
-    'bdv_bn_apply': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, P]),
-    'bdv_bn_backward': (c_int, [P, P, P, P, P, P, P, P, P, c_float, c_int64, c_int, c_int, P, c_int, P, P, P, c_size_t, P]),
-    'bdv_bn_backward_maxpool': (c_int, [P, P, P, P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, P, c_size_t, P]),
-    'bdv_relu_bwd': (c_int, [P, P, P, P, c_int64, P]),
-    'bdv_add': (c_int, [P, P, P, c_int64, P]),
+    'bdv_bn_apply': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
+    'bdv_bn_backward': (c_int, [P, P, P, P, P, P, P, P, P, c_float, c_int64, c_int, c_int, P, c_int, P, P, P, c_size_t, c_int, P]),
+    'bdv_bn_backward_maxpool': (c_int, [P, P, P, P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, P, c_size_t, c_int, P]),
+    'bdv_relu_bwd': (c_int, [P, P, P, P, c_int64, c_int, P]),
+    'bdv_add': (c_int, [P, P, P, c_int64, c_int, P]),
     'bdv_nchw3_to_nhwc4': (c_int, [P, P, c_int, c_int, c_int, P]),
-    'bdv_maxpool_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
-    'bdv_maxpool_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_maxpool_fwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'bdv_maxpool_bwd': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'bdv_maxpool_t2_fwd': (c_int, [P, P, P, c_int64, c_int64, P]),
     'bdv_maxpool_t2_bwd': (c_int, [P, P, P, c_int64, c_int64, P]),
-    'bdv_bn_relu_maxpool_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    'bdv_avgpool_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
-    'bdv_avgpool_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'bdv_bn_relu_maxpool_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'bdv_avgpool_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_avgpool_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_bgmix_normalize_u8': (c_int, [P, P, P, c_float, _F3, _F3, _F3, P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_crop_normalize_u8': (c_int, [P, P, c_int, c_int, c_int, _F3, _F3, P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_lsc_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
@@ -117,8 +117,8 @@ SIGNATURES = {
     'bdv_randaug_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'bdv_randaug_apply': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'bdv_reduce_workspace_bytes': (c_size_t, []),
-    'bdv_kd_mse_fwd': (c_int, [P, P, P, c_int64, P, c_size_t, P]),
-    'bdv_kd_mse_bwd': (c_int, [P, P, P, c_float, P, c_int64, P]),
+    'bdv_kd_mse_fwd': (c_int, [P, P, P, c_int64, P, c_size_t, c_int, P]),
+    'bdv_kd_mse_bwd': (c_int, [P, P, P, c_float, P, c_int64, c_int, P]),
     'bdv_multi_sqnorm': (c_int, [P, P, c_int, P, P, c_size_t, P]),
     'bdv_clip_coef': (c_int, [P, c_float, c_float, P, P]),
     'bdv_multi_sgd': (c_int, [P, P, P, P, P, P, c_int, c_float, c_float, P, P]),

@@ -166,15 +166,6 @@ __global__ void bn_eval_params_kernel(int C, const float* __restrict__ gamma, co
 // their place in L2 / Infinity Cache: 54.39 -> 53.51 ms per training step in one process (tools/ab_step.py).
 // (second box: plain 55.20, level 1 54.68, level 2 54.50).  BDVCIL_BN_NT: 0 = plain loads, 1 = y / dout of bn_apply and
 // bn_bwd_apply, 2 (default) = also the residual of bn_apply (the block input: next read in the backward pass).
-typedef float f32x4_nt __attribute__((ext_vector_type(4)));
-template <bool NT>
-__device__ __forceinline__ float4 ld4(const float4* __restrict__ p) {
-  if (NT) {
-    const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-  }
-  return *p;
-}
 static int bn_nt_level() {  // read per call (a getenv is nothing beside a launch): tools/ab_step.py flips it between rounds
   const char* e = getenv("BDVCIL_BN_NT");
   return e != nullptr ? atoi(e) : 2;
@@ -205,23 +196,24 @@ __device__ __forceinline__ float4 apply_nibble(float4 g, unsigned nib) {
 
 // res_scale / res_shift (optional): the residual is itself a raw conv output that still needs its own BatchNorm
 // (the downsample branch of a block): r = res * res_scale + res_shift is formed here instead of in a pass of its own.
-template <bool RELU, bool RES, bool NT = false, bool NTR = false>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
-                                                        const float4* __restrict__ shift, const float4* __restrict__ res,
+// ES: bytes per element of y / res / out (common.h: 4 = fp32, 2 = bf16 storage)
+template <bool RELU, bool RES, bool NT = false, bool NTR = false, int ES = 4>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ y, const float4* __restrict__ scale,
+                                                        const float4* __restrict__ shift, const void* __restrict__ res,
                                                         const float4* __restrict__ res_scale, const float4* __restrict__ res_shift,
-                                                        float4* __restrict__ out, uint32_t* __restrict__ mask, int64_t n4, int CV) {
+                                                        void* __restrict__ out, uint32_t* __restrict__ mask, int64_t n4, int CV) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   // n4 is a multiple of 8 (C % 32 == 0) and so is the stride: the 8 lanes of one mask word stay together
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const int c4 = (int)(i % CV);
-    const float4 v = ld4<NT>(y + i), sc = scale[c4], sh = shift[c4];
+    const float4 v = act_ld4<ES, NT>(y, i), sc = scale[c4], sh = shift[c4];
     float4 o;
     o.x = fmaf(v.x, sc.x, sh.x);   // explicit: the conv loaders that apply this BatchNorm themselves (PRE) use the same expression
     o.y = fmaf(v.y, sc.y, sh.y);
     o.z = fmaf(v.z, sc.z, sh.z);
     o.w = fmaf(v.w, sc.w, sh.w);
     if (RES) {
-      float4 r = ld4<NTR>(res + i);
+      float4 r = act_ld4<ES, NTR>(res, i);
       if (res_scale != nullptr) {
         const float4 rs = res_scale[c4], rb = res_shift[c4];
         r.x = r.x * rs.x + rb.x; r.y = r.y * rs.y + rb.y; r.z = r.z * rs.z + rb.z; r.w = r.w * rs.w + rb.w;
@@ -238,15 +230,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
       }
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
-    out[i] = o;
+    act_st4<ES>(out, i, o);
   }
 }
 
 // ---- backward ----------------------------------------------------------------------------
 // RELU: 0 = none, 1 = the forward's 1-bit mask, 2 = the sign derived from y (rscale / rshift: the unit's mask was never written)
-template <int RELU>
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dout, const uint32_t* __restrict__ mask,
-                                                              const float* __restrict__ y, const float* __restrict__ mean,
+template <int RELU, int ES = 4>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const void* __restrict__ dout, const uint32_t* __restrict__ mask,
+                                                              const void* __restrict__ y, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* __restrict__ p1,
                                                               float* __restrict__ p2, int64_t M, int C, int CVB, int RL,
                                                               int rows_per_block, const float* __restrict__ rscale,
@@ -264,8 +256,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   for (int64_t r = r0 + rl; r < r1; r += RL) {
     const int64_t i = r * CV + c4;
-    float4 g = reinterpret_cast<const float4*>(dout)[i];
-    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    float4 g = act_ld4<ES>(dout, i);
+    const float4 v = act_ld4<ES>(y, i);
     if (RELU == 1) g = apply_nibble(g, mask_nibble(mask, i));
     if (RELU == 2) g = apply_nibble(g, derive_nibble(v, reinterpret_cast<const float4*>(rscale)[c4], reinterpret_cast<const float4*>(rshift)[c4]));
     s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
@@ -306,17 +298,17 @@ __global__ __launch_bounds__(4 * FIN_LANES) void bn_bwd_finalize_kernel(const fl
   coef[2 * C + c] = (float)(s2 / (double)M);
 }
 
-template <int RELU, bool NT = false>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restrict__ dout, const uint32_t* __restrict__ mask,
-                                                            const float4* __restrict__ y, const float4* __restrict__ mean,
+template <int RELU, bool NT = false, int ES = 4>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ dout, const uint32_t* __restrict__ mask,
+                                                            const void* __restrict__ y, const float4* __restrict__ mean,
                                                             const float4* __restrict__ invstd, const float4* __restrict__ coef,
-                                                            float4* __restrict__ dy, int64_t n4, int CV,
+                                                            void* __restrict__ dy, int64_t n4, int CV,
                                                             const float4* __restrict__ rscale, const float4* __restrict__ rshift) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const int c4 = (int)(i % CV);
-    float4 g = ld4<NT>(dout + i);
-    const float4 v = ld4<NT>(y + i), mu = mean[c4], is = invstd[c4];
+    float4 g = act_ld4<ES, NT>(dout, i);
+    const float4 v = act_ld4<ES, NT>(y, i), mu = mean[c4], is = invstd[c4];
     if (RELU == 1) g = apply_nibble(g, mask_nibble(mask, i));
     if (RELU == 2) g = apply_nibble(g, derive_nibble(v, rscale[c4], rshift[c4]));
     const float4 a = coef[c4], b = coef[CV + c4], c = coef[2 * CV + c4];
@@ -325,7 +317,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
     d.y = a.y * (g.y - b.y - ((v.y - mu.y) * is.y) * c.y);
     d.z = a.z * (g.z - b.z - ((v.z - mu.z) * is.z) * c.z);
     d.w = a.w * (g.w - b.w - ((v.w - mu.w) * is.w) * c.w);
-    dy[i] = d;
+    act_st4<ES>(dy, i, d);
   }
 }
 
@@ -333,8 +325,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
 // The gradient entering the BN+ReLU is the max-pool backward of dpool; it is gathered on the fly (pool_bwd_gather2x2)
 // in both passes instead of being materialised: thread = (2x2 input block, 4 channels), grid.y strides (frame, block
 // row).  256 % CV == 0, so a thread keeps its 4 channels and the per-block reduction groups threads by tid % CV.
-template <bool APPLY>
-__global__ __launch_bounds__(256) void bn_bwd_pool_kernel(const float4* __restrict__ dpool, const uchar4* __restrict__ idx,
+template <bool APPLY, int ESD = 4>
+__global__ __launch_bounds__(256) void bn_bwd_pool_kernel(const void* __restrict__ dpool, const uchar4* __restrict__ idx,
                                                            const uint32_t* __restrict__ mask, const float4* __restrict__ y,
                                                            const float4* __restrict__ mean, const float4* __restrict__ invstd,
                                                            const float4* __restrict__ coef, float4* __restrict__ dy,
@@ -360,7 +352,7 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(const float4* __restri
       const int j = q / CV;  // q % CV == c4
       const bool right = j + 1 < Wo, w1ok = 2 * j + 1 < W;
       float4 g[4];
-      pool_bwd_gather2x2(dpool, idx, obase + (i * Wo + j) * CV + c4, CV, Wo, right, down, g);
+      pool_bwd_gather2x2<ESD>(dpool, idx, obase + (i * Wo + j) * CV + c4, CV, Wo, right, down, g);
       const int64_t p00 = ibase + ((2 * i) * W + 2 * j) * CV + c4;
       const int64_t pix[4] = {p00, p00 + CV, p00 + (int64_t)W * CV, p00 + (int64_t)(W + 1) * CV};
       const bool ok[4] = {true, w1ok, h1ok, h1ok && w1ok};
@@ -401,25 +393,27 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_kernel(const float4* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void relu_bwd_kernel(const float4* __restrict__ dout, const uint32_t* __restrict__ mask,
-                                                        const float4* __restrict__ add, float4* __restrict__ g, int64_t n4) {
+template <int ES = 4>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const void* __restrict__ dout, const uint32_t* __restrict__ mask,
+                                                        const void* __restrict__ add, void* __restrict__ g, int64_t n4) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 d = apply_nibble(dout[i], mask_nibble(mask, i));
+    float4 d = apply_nibble(act_ld4<ES>(dout, i), mask_nibble(mask, i));
     if (add != nullptr) {
-      const float4 a = add[i];
+      const float4 a = act_ld4<ES>(add, i);
       d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
     }
-    g[i] = d;
+    act_st4<ES>(g, i, d);
   }
 }
 
-__global__ __launch_bounds__(256) void add_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
-                                                   float4* __restrict__ out, int64_t n4) {
+template <int ES = 4>
+__global__ __launch_bounds__(256) void add_kernel(const void* __restrict__ a, const void* __restrict__ b,
+                                                   void* __restrict__ out, int64_t n4) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const float4 x = a[i], y = b[i];
-    out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    const float4 x = act_ld4<ES>(a, i), y = act_ld4<ES>(b, i);
+    act_st4<ES>(out, i, make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
   }
 }
 
@@ -484,9 +478,11 @@ extern "C" int bdv_bn_eval_params(int C, const float* gamma, const float* beta, 
   return BDV_OK;
 }
 
-extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale,
-                            const float* res_shift, float* out, uint32_t* relu_mask, int64_t M, int C, int relu, void* stream) {
+extern "C" int bdv_bn_apply(const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
+                            const float* res_shift, void* out, uint32_t* relu_mask, int64_t M, int C, int relu, int act_dtype,
+                            void* stream) {
   BDV_REQUIRE(y && scale && shift && out, "bdv_bn_apply: null pointer");
+  BDV_REQUIRE_ACT(act_dtype, "bdv_bn_apply");
   BDV_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (res_scale == nullptr || res != nullptr),
               "bdv_bn_apply: res_scale and res_shift come together and need res");
   BDV_REQUIRE(bdv_aligned16(res_scale) && bdv_aligned16(res_shift), "bdv_bn_apply: alignment");
@@ -498,26 +494,30 @@ extern "C" int bdv_bn_apply(const float* y, const float* scale, const float* shi
   const int CV = C / 4;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(ew_grid(n4)), blk(256);
-  const float4 *y4 = (const float4*)y, *sc = (const float4*)scale, *sh = (const float4*)shift, *r4 = (const float4*)res;
+  const float4 *sc = (const float4*)scale, *sh = (const float4*)shift;
   const float4 *rs = (const float4*)res_scale, *rb = (const float4*)res_shift;
-  float4* o4 = (float4*)out;
-  if (relu && res && bn_nt_level() >= 2) hipLaunchKernelGGL((bn_apply_kernel<true, true, true, true>), grid, blk, 0, s, y4, sc, sh, r4, rs, rb, o4, relu_mask, n4, CV);
-  else if (relu && res && bn_nt_enabled()) hipLaunchKernelGGL((bn_apply_kernel<true, true, true>), grid, blk, 0, s, y4, sc, sh, r4, rs, rb, o4, relu_mask, n4, CV);
-  else if (relu && bn_nt_enabled()) hipLaunchKernelGGL((bn_apply_kernel<true, false, true>), grid, blk, 0, s, y4, sc, sh, r4, rs, rb, o4, relu_mask, n4, CV);
-  else if (relu && res) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, blk, 0, s, y4, sc, sh, r4, rs, rb, o4, relu_mask, n4, CV);
-  else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, blk, 0, s, y4, sc, sh, r4, rs, rb, o4, relu_mask, n4, CV);
-  else if (res) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, blk, 0, s, y4, sc, sh, r4, rs, rb, o4, relu_mask, n4, CV);
-  else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, blk, 0, s, y4, sc, sh, r4, rs, rb, o4, relu_mask, n4, CV);
+#define BDV_APPLY(...) hipLaunchKernelGGL((bn_apply_kernel<__VA_ARGS__, ES>), grid, blk, 0, s, y, sc, sh, res, rs, rb, out, relu_mask, n4, CV)
+  BDV_ACT_SWITCH(act_dtype, ES, {
+    if (relu && res && bn_nt_level() >= 2) BDV_APPLY(true, true, true, true);
+    else if (relu && res && bn_nt_enabled()) BDV_APPLY(true, true, true, false);
+    else if (relu && bn_nt_enabled()) BDV_APPLY(true, false, true, false);
+    else if (relu && res) BDV_APPLY(true, true, false, false);
+    else if (relu) BDV_APPLY(true, false, false, false);
+    else if (res) BDV_APPLY(false, true, false, false);
+    else BDV_APPLY(false, false, false, false);
+  });
+#undef BDV_APPLY
   BDV_LAUNCH_CHECK("bdv_bn_apply");
   return BDV_OK;
 }
 
-extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, const float* y, const float* gamma,
-                               const float* save_mean, const float* save_invstd, float* dy, float* dgamma,
+extern "C" int bdv_bn_backward(const void* dout, const uint32_t* relu_mask, const void* y, const float* gamma,
+                               const float* save_mean, const float* save_invstd, void* dy, float* dgamma,
                                float* dbeta, float beta_acc, int64_t M, int C, int relu, const float* stat_partial,
                                int stat_rows, const float* relu_scale, const float* relu_shift, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               size_t workspace_bytes, int act_dtype, void* stream) {
   BDV_REQUIRE(dout && y && gamma && save_mean && save_invstd && dy && workspace, "bdv_bn_backward: null pointer");
+  BDV_REQUIRE_ACT(act_dtype, "bdv_bn_backward");
   BDV_REQUIRE(stat_partial == nullptr || (stat_rows > 0 && bdv_aligned16(stat_partial)), "bdv_bn_backward: bad stat_partial");
   const bool derive = relu && relu_mask == nullptr && relu_scale != nullptr;
   BDV_REQUIRE(!relu || derive || (relu_mask && C % 32 == 0), "bdv_bn_backward: relu needs the forward ReLU mask (C %% 32 == 0) or relu_scale / relu_shift");
@@ -541,15 +541,15 @@ extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, con
     q2 = stat_partial + (size_t)stat_rows * C;
     rows = stat_rows;
   } else {
-    if (derive)
-      hipLaunchKernelGGL((bn_bwd_partial_kernel<2>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean,
-                         save_invstd, p1, p2, M, C, b.CVB, b.RL, b.rows_per_block, relu_scale, relu_shift);
-    else if (relu)
-      hipLaunchKernelGGL((bn_bwd_partial_kernel<1>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean,
-                         save_invstd, p1, p2, M, C, b.CVB, b.RL, b.rows_per_block, relu_scale, relu_shift);
-    else
-      hipLaunchKernelGGL((bn_bwd_partial_kernel<0>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean,
-                         save_invstd, p1, p2, M, C, b.CVB, b.RL, b.rows_per_block, relu_scale, relu_shift);
+#define BDV_BWD_PARTIAL(RELU_)                                                                                                  \
+  hipLaunchKernelGGL((bn_bwd_partial_kernel<RELU_, ES>), dim3(b.RB, b.CC), dim3(256), 0, s, dout, relu_mask, y, save_mean,     \
+                     save_invstd, p1, p2, M, C, b.CVB, b.RL, b.rows_per_block, relu_scale, relu_shift)
+    BDV_ACT_SWITCH(act_dtype, ES, {
+      if (derive) BDV_BWD_PARTIAL(2);
+      else if (relu) BDV_BWD_PARTIAL(1);
+      else BDV_BWD_PARTIAL(0);
+    });
+#undef BDV_BWD_PARTIAL
     BDV_LAUNCH_CHECK("bdv_bn_backward(partial)");
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(4 * FIN_LANES), 0, s, q1, q2, rows, M, C, gamma, save_invstd, dgamma,
@@ -559,23 +559,26 @@ extern "C" int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, con
   const dim3 grid(ew_grid(n4)), blk(256);
   const float4 *rs4 = (const float4*)relu_scale, *rh4 = (const float4*)relu_shift;
 #define BDV_BWD_APPLY(RELU_, NT_)                                                                                              \
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<RELU_, NT_>), grid, blk, 0, s, (const float4*)dout, relu_mask, (const float4*)y,     \
-                     (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy, n4, C / 4, rs4, rh4)
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<RELU_, NT_, ES>), grid, blk, 0, s, dout, relu_mask, y,                               \
+                     (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, dy, n4, C / 4, rs4, rh4)
   const bool nt = bn_nt_enabled();
-  if (derive) { if (nt) BDV_BWD_APPLY(2, true); else BDV_BWD_APPLY(2, false); }
-  else if (relu) { if (nt) BDV_BWD_APPLY(1, true); else BDV_BWD_APPLY(1, false); }
-  else BDV_BWD_APPLY(0, false);
+  BDV_ACT_SWITCH(act_dtype, ES, {
+    if (derive) { if (nt) BDV_BWD_APPLY(2, true); else BDV_BWD_APPLY(2, false); }
+    else if (relu) { if (nt) BDV_BWD_APPLY(1, true); else BDV_BWD_APPLY(1, false); }
+    else BDV_BWD_APPLY(0, false);
+  });
 #undef BDV_BWD_APPLY
   BDV_LAUNCH_CHECK("bdv_bn_backward(apply)");
   return BDV_OK;
 }
 
-extern "C" int bdv_bn_backward_maxpool(const float* dpool, const uint8_t* pool_idx, const uint32_t* relu_mask, const float* y,
+extern "C" int bdv_bn_backward_maxpool(const void* dpool, const uint8_t* pool_idx, const uint32_t* relu_mask, const float* y,
                                        const float* gamma, const float* save_mean, const float* save_invstd, float* dy,
                                        float* dgamma, float* dbeta, float beta_acc, int N, int H, int W, int C, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+                                       size_t workspace_bytes, int dpool_dtype, void* stream) {
   BDV_REQUIRE(dpool && pool_idx && relu_mask && y && gamma && save_mean && save_invstd && dy && workspace,
               "bdv_bn_backward_maxpool: null pointer");
+  BDV_REQUIRE_ACT(dpool_dtype, "bdv_bn_backward_maxpool");
   BDV_REQUIRE(N > 0 && H > 1 && W > 1 && C >= 32 && C % 32 == 0 && 256 % (C / 4) == 0,
               "bdv_bn_backward_maxpool: unsupported shape (C must be 32, 64, 128, 256, 512 or 1024)");
   BDV_REQUIRE(bdv_aligned16(dpool) && bdv_aligned16(y) && bdv_aligned16(dy) && bdv_aligned16(workspace) &&
@@ -599,36 +602,38 @@ extern "C" int bdv_bn_backward_maxpool(const float* dpool, const uint8_t* pool_i
   float* coef = p2 + MAX_RB_TIMES_C;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(gx, gy), blk(256);
-  hipLaunchKernelGGL((bn_bwd_pool_kernel<false>), grid, blk, 0, s, (const float4*)dpool, (const uchar4*)pool_idx, relu_mask,
+  BDV_ACT_SWITCH(dpool_dtype, ES, hipLaunchKernelGGL((bn_bwd_pool_kernel<false, ES>), grid, blk, 0, s, dpool, (const uchar4*)pool_idx, relu_mask,
                      (const float4*)y, (const float4*)save_mean, (const float4*)save_invstd, (const float4*)nullptr,
-                     (float4*)nullptr, p1, p2, N, H, W, CV, Ho, Wo);
+                     (float4*)nullptr, p1, p2, N, H, W, CV, Ho, Wo));
   BDV_LAUNCH_CHECK("bdv_bn_backward_maxpool(partial)");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(4 * FIN_LANES), 0, s, (const float*)p1, (const float*)p2, gx * gy, M, C,
                      gamma, save_invstd, dgamma, dbeta, beta_acc, coef);
   BDV_LAUNCH_CHECK("bdv_bn_backward_maxpool(finalize)");
-  hipLaunchKernelGGL((bn_bwd_pool_kernel<true>), grid, blk, 0, s, (const float4*)dpool, (const uchar4*)pool_idx, relu_mask,
+  BDV_ACT_SWITCH(dpool_dtype, ES, hipLaunchKernelGGL((bn_bwd_pool_kernel<true, ES>), grid, blk, 0, s, dpool, (const uchar4*)pool_idx, relu_mask,
                      (const float4*)y, (const float4*)save_mean, (const float4*)save_invstd, (const float4*)coef, (float4*)dy,
-                     (float*)nullptr, (float*)nullptr, N, H, W, CV, Ho, Wo);
+                     (float*)nullptr, (float*)nullptr, N, H, W, CV, Ho, Wo));
   BDV_LAUNCH_CHECK("bdv_bn_backward_maxpool(apply)");
   return BDV_OK;
 }
 
-extern "C" int bdv_relu_bwd(const float* dout, const uint32_t* relu_mask, const float* add, float* g, int64_t numel, void* stream) {
+extern "C" int bdv_relu_bwd(const void* dout, const uint32_t* relu_mask, const void* add, void* g, int64_t numel, int act_dtype,
+                            void* stream) {
   BDV_REQUIRE(dout && relu_mask && g && numel > 0 && numel % 32 == 0, "bdv_relu_bwd: bad argument");
+  BDV_REQUIRE_ACT(act_dtype, "bdv_relu_bwd");
   BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(g) && (!add || bdv_aligned16(add)), "bdv_relu_bwd: alignment");
   const int64_t n4 = numel / 4;
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout,
-                     relu_mask, (const float4*)add, (float4*)g, n4);
+  BDV_ACT_SWITCH(act_dtype, ES, hipLaunchKernelGGL((relu_bwd_kernel<ES>), dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, dout,
+                     relu_mask, add, g, n4));
   BDV_LAUNCH_CHECK("bdv_relu_bwd");
   return BDV_OK;
 }
 
-extern "C" int bdv_add(const float* a, const float* b, float* out, int64_t numel, void* stream) {
+extern "C" int bdv_add(const void* a, const void* b, void* out, int64_t numel, int act_dtype, void* stream) {
   BDV_REQUIRE(a && b && out && numel > 0 && numel % 4 == 0, "bdv_add: bad argument");
+  BDV_REQUIRE_ACT(act_dtype, "bdv_add");
   BDV_REQUIRE(bdv_aligned16(a) && bdv_aligned16(b) && bdv_aligned16(out), "bdv_add: alignment");
   const int64_t n4 = numel / 4;
-  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b,
-                     (float4*)out, n4);
+  BDV_ACT_SWITCH(act_dtype, ES, hipLaunchKernelGGL((add_kernel<ES>), dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, a, b, out, n4));
   BDV_LAUNCH_CHECK("bdv_add");
   return BDV_OK;
 }

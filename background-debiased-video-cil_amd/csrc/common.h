@@ -45,6 +45,60 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- activation storage ------------------------------------------------------------------------------------------------
+// ES = bytes per activation element: 4 = fp32 (default everywhere), 2 = bf16 storage (BDV_ACT_BF16: BASELINE config 5, the
+// reduced-precision mode).  A bf16 value widens to fp32 exactly (16-bit shift); a store rounds to nearest-even
+// (v_cvt_pk_bf16_f32).  Tensors are addressed in groups of 4 consecutive elements: 16-byte (fp32) or 8-byte (bf16) accesses.
+typedef __bf16 bdv_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float bdv_f32x2_t __attribute__((ext_vector_type(2)));
+typedef float bdv_f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned bdv_u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bdv_pack_bf16x2(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((bdv_f32x2_t){a, b}, bdv_bf16x2_t));
+}
+__device__ __forceinline__ float4 bdv_widen_bf16x4(unsigned lo, unsigned hi) {
+  return make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                     __uint_as_float(hi & 0xffff0000u));
+}
+template <int ES, bool NT = false>
+__device__ __forceinline__ float4 act_ld4(const void* __restrict__ base, int64_t i4) {
+  if constexpr (ES == 4) {
+    const float4* p = reinterpret_cast<const float4*>(base) + i4;
+    if constexpr (NT) {
+      const bdv_f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const bdv_f32x4_t*>(p));
+      return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+      return *p;
+    }
+  } else {
+    const bdv_u32x2_t* p = reinterpret_cast<const bdv_u32x2_t*>(base) + i4;
+    bdv_u32x2_t v;
+    if constexpr (NT) v = __builtin_nontemporal_load(p);
+    else v = *p;
+    return bdv_widen_bf16x4(v.x, v.y);
+  }
+}
+template <int ES>
+__device__ __forceinline__ void act_st4(void* __restrict__ base, int64_t i4, const float4 v) {
+  if constexpr (ES == 4) {
+    reinterpret_cast<float4*>(base)[i4] = v;
+  } else {
+    reinterpret_cast<bdv_u32x2_t*>(base)[i4] = (bdv_u32x2_t){bdv_pack_bf16x2(v.x, v.y), bdv_pack_bf16x2(v.z, v.w)};
+  }
+}
+// host-side dispatch on bdv act_dtype: BDV_ACT_SWITCH(dt, ES, launch<ES>(...))
+#define BDV_ACT_SWITCH(dt, ES, ...)  \
+  do {                               \
+    if ((dt) == BDV_ACT_BF16) {      \
+      constexpr int ES = 2;          \
+      __VA_ARGS__;                   \
+    } else {                         \
+      constexpr int ES = 4;          \
+      __VA_ARGS__;                   \
+    }                                \
+  } while (0)
+#define BDV_REQUIRE_ACT(dt, name) BDV_REQUIRE((dt) == BDV_ACT_F32 || (dt) == BDV_ACT_BF16, "%s: act_dtype %d (BDV_ACT_F32 = 0 | BDV_ACT_BF16 = 1)", name, (int)(dt))
+
 // ---- MaxPool2d(3, 2, 1) backward as a gather (shared by maxpool_bwd and the fused stem BatchNorm backward) ----------
 // The 2x2 input block (2i..2i+1, 2j..2j+1) of channels c4 is covered by exactly the windows (i,j), (i,j+1), (i+1,j),
 // (i+1,j+1); a pixel takes a window's gradient when the stored arg-max code equals its position r*3+s inside that
@@ -56,18 +110,19 @@ __device__ __forceinline__ void pool_take(float4& g, const uchar4 t, const float
   if (t.w == me) g.w += d.w;
 }
 
-__device__ __forceinline__ void pool_bwd_gather2x2(const float4* __restrict__ dout, const uchar4* __restrict__ idx, int64_t o00,
+template <int ES = 4>
+__device__ __forceinline__ void pool_bwd_gather2x2(const void* __restrict__ dout, const uchar4* __restrict__ idx, int64_t o00,
                                                    int CV, int Wo, bool right, bool down, float4 (&g)[4]) {
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const uchar4 none = make_uchar4(255, 255, 255, 255);
   const uchar4 t00 = idx[o00];
-  const float4 d00 = dout[o00];
+  const float4 d00 = act_ld4<ES>(dout, o00);
   const uchar4 t01 = right ? idx[o00 + CV] : none;
-  const float4 d01 = right ? dout[o00 + CV] : z4;
+  const float4 d01 = right ? act_ld4<ES>(dout, o00 + CV) : z4;
   const uchar4 t10 = down ? idx[o00 + Wo * CV] : none;
-  const float4 d10 = down ? dout[o00 + Wo * CV] : z4;
+  const float4 d10 = down ? act_ld4<ES>(dout, o00 + Wo * CV) : z4;
   const uchar4 t11 = (down && right) ? idx[o00 + (Wo + 1) * CV] : none;
-  const float4 d11 = (down && right) ? dout[o00 + (Wo + 1) * CV] : z4;
+  const float4 d11 = (down && right) ? act_ld4<ES>(dout, o00 + (Wo + 1) * CV) : z4;
   g[0] = g[1] = g[2] = g[3] = z4;
   pool_take(g[0], t00, d00, 4);  // (2i, 2j): centre of window (i,j)
   pool_take(g[1], t01, d01, 3);  // (2i, 2j+1): (r=1,s=0) of (i,j+1), then (1,2) of (i,j)

@@ -52,6 +52,27 @@ __device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t rsrc, int vof
   __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, voff, 0, 0);
 }
 
+// Activation access of the plane kernels by element size ES (common.h): byte offsets are already scaled by ES; a thread's unit
+// is 4 consecutive channels = 16 bytes of fp32 or 8 bytes of bf16 (widened exactly / rounded to nearest-even).
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+template <int ES>
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t rsrc, int voff) {
+  if constexpr (ES == 4) {
+    return buf_load16(rsrc, voff, 0);
+  } else {
+    const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0);
+    return bdv_widen_bf16x4(v.x, v.y);
+  }
+}
+template <int ES>
+__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t rsrc, int voff, float4 v) {
+  if constexpr (ES == 4) {
+    buf_store16(rsrc, voff, v);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b64((u32x2v){bdv_pack_bf16x2(v.x, v.y), bdv_pack_bf16x2(v.z, v.w)}, rsrc, voff, 0, 0);
+  }
+}
+
 // q = m / d, r = m % d for 0 <= m < 2^22 with a float reciprocal and one correction step each way
 __device__ __forceinline__ void fast_divmod(int m, int d, float rcp, int& q, int& r) {
   q = (int)((float)m * rcp);
@@ -217,7 +238,7 @@ __device__ __forceinline__ void fprop_store(float* __restrict__ y, const Geom& g
 // mask are read at that destination: every dx element is still written exactly once), reduced over the tile in fixed
 // order and written to partial[0 | 1][mt][Cin]; the separate statistics pass over dx, y and the mask disappears.
 struct BnStat {
-  const float* y;
+  const void* y;         // conv output of the unit whose BatchNorm-backward statistics are taken (element type = the kernel's ES)
   const uint32_t* mask;  // may be null (no ReLU, or the sign is derived from y: rscale)
   const float* mean;
   const float* invstd;
@@ -313,9 +334,9 @@ __device__ __forceinline__ void staged_epilogue(const f32x16 (&acc)[BM / WM / 32
 
 // DERIVE: the ReLU sign of the statistics may come from the conv output itself (BnStat::rscale); compiled out of the fp32-MFMA
 // kernels, whose 168-register budget has no room for it (the model only derives signs in the bf16-piece arithmetic).
-template <int BM, int BN, int WM, int WN, bool DERIVE = true, class RowMap>
+template <int BM, int BN, int WM, int WN, bool DERIVE = true, int ES = 4, class RowMap>
 __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ smem, int tid,
-                                               float* __restrict__ dx, const float* __restrict__ add_src,
+                                               void* __restrict__ dx, const void* __restrict__ add_src,
                                                const uint32_t* __restrict__ add_mask, const Geom& g, int mt, int nt, int Mrows,
                                                const BnStat& stat, RowMap&& rowmap) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -326,17 +347,18 @@ __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32]
   const int wm = wave / WN, wn0 = (wave % WN) * 32;
   const int HW = g.H * g.W;
   const float rcp_HW = 1.0f / (float)HW;
-  const int total_bytes = g.N * HW * g.Cin * 4;
+  const int total_bytes = g.N * HW * g.Cin * ES;
+  const int mask_bytes = g.N * HW * (g.Cin / 8);
   const __amdgpu_buffer_rsrc_t dxr = __builtin_amdgcn_make_buffer_rsrc((void*)dx, 0, total_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t adr =
       __builtin_amdgcn_make_buffer_rsrc((void*)(add_src ? add_src : dx), 0, add_src ? total_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t amr =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(add_mask ? (const void*)add_mask : (const void*)dx), 0, add_mask ? total_bytes / 32 : 0, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)(add_mask ? (const void*)add_mask : (const void*)dx), 0, add_mask ? mask_bytes : 0, 0x00020000);
   const bool do_stat = stat.y != nullptr;
   const __amdgpu_buffer_rsrc_t syr =
       __builtin_amdgcn_make_buffer_rsrc((void*)(do_stat ? stat.y : dx), 0, do_stat ? total_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t smr = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(do_stat && stat.mask ? (const void*)stat.mask : (const void*)dx), 0, do_stat && stat.mask ? total_bytes / 32 : 0, 0x00020000);
+      (void*)(do_stat && stat.mask ? (const void*)stat.mask : (const void*)dx), 0, do_stat && stat.mask ? mask_bytes : 0, 0x00020000);
   // the thread's 4 columns are the same for every piece (256 % V == 0)
   const int col = nt * BN + 4 * (tid % V);
   const int cls = shift_class(col, g.fold);
@@ -373,26 +395,26 @@ __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32]
           zero = !inside;
         }
         const int o = drow * g.Cin + col;
-        off[u] = ok ? o * 4 : kOOB;
+        off[u] = ok ? o * ES : kOOB;
         const float4 t4 = *reinterpret_cast<const float4*>(smem + lr * BN + 4 * (tid % V));
         v[u] = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : t4;
-        a[u] = buf_load16(adr, off[u], 0);  // zeros when there is no add_src
+        a[u] = buf_ld4<ES>(adr, off[u]);  // zeros when there is no add_src
         am[u] = add_mask ? __builtin_amdgcn_raw_buffer_load_b32(amr, ok ? (o >> 5) << 2 : kOOB, 0, 0) : 0xffffffffu;
         if (do_stat) {
-          yv[u] = buf_load16(syr, off[u], 0);
+          yv[u] = buf_ld4<ES>(syr, off[u]);
           sm[u] = stat.mask ? __builtin_amdgcn_raw_buffer_load_b32(smr, ok ? (o >> 5) << 2 : kOOB, 0, 0) : 0xffffffffu;
         }
       }
 #pragma unroll
       for (int u = 0; u < HB; ++u) {
-        const int sh = (off[u] >> 2) & 31;  // bit position of the piece's first channel in its mask word
+        const int sh = (off[u] / ES) & 31;  // bit position of the piece's first channel in its mask word
         const unsigned nib = (am[u] >> sh) & 0xFu;
         float4 r = v[u];
         r.x += (nib & 1u) ? a[u].x : 0.f;
         r.y += (nib & 2u) ? a[u].y : 0.f;
         r.z += (nib & 4u) ? a[u].z : 0.f;
         r.w += (nib & 8u) ? a[u].w : 0.f;
-        buf_store16(dxr, off[u], r);
+        buf_st4<ES>(dxr, off[u], r);
         if (do_stat && off[u] != kOOB) {
           const unsigned sn = (DERIVE && stat.rscale != nullptr) ? StatAcc::sign_bits(stat, col, yv[u]) : (sm[u] >> sh) & 0xFu;
           float4 gq;
@@ -452,7 +474,7 @@ struct FpropEpi {
   int MT;
   const float* scale;  // null: plain store
   const float* shift;
-  const float* res;    // optional residual, same shape as y
+  const void* res;     // optional residual, same shape and element type as y
   int relu;
   // BatchNorm + ReLU of the PRODUCER applied to the activation operand in the loader (conv_fprop_pl_kernel<..., PRE>):
   // a = max(x * pre_scale[ci] + pre_shift[ci], 0)
@@ -460,9 +482,9 @@ struct FpropEpi {
   const float* pre_shift;
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int ES = 4>
 __device__ __forceinline__ void fprop_affine_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ smem,
-                                                      float* __restrict__ y, const Geom& g, const FpropEpi& epi, int mt, int nt,
+                                                      void* __restrict__ y, const Geom& g, const FpropEpi& epi, int mt, int nt,
                                                       int tid) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NT = 64 * WM * WN;
@@ -471,10 +493,10 @@ __device__ __forceinline__ void fprop_affine_epilogue(const f32x16 (&acc)[BM / W
   constexpr int HB = PER < 4 ? PER : 4;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn0 = (wave % WN) * 32;
-  const int total_bytes = g.M * g.Cout * 4;
+  const int total_bytes = g.M * g.Cout * ES;
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, total_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(epi.res ? epi.res : y), 0, epi.res ? total_bytes : 0, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)(epi.res ? epi.res : (const void*)y), 0, epi.res ? total_bytes : 0, 0x00020000);
   const int col = nt * BN + 4 * (tid % V);  // the thread's 4 columns are the same for every piece (256 % V == 0)
   const float4 sc = *reinterpret_cast<const float4*>(epi.scale + col);
   const float4 sh = *reinterpret_cast<const float4*>(epi.shift + col);
@@ -494,9 +516,9 @@ __device__ __forceinline__ void fprop_affine_epilogue(const f32x16 (&acc)[BM / W
       for (int u = 0; u < HB; ++u) {
         const int lr = (tid + NT * (q0 + u)) / V;
         const int row = mt * BM + 32 * WM * i + lr;
-        off[u] = row < g.M ? (row * g.Cout + col) * 4 : kOOB;
+        off[u] = row < g.M ? (row * g.Cout + col) * ES : kOOB;
         v[u] = *reinterpret_cast<const float4*>(smem + lr * BN + 4 * (tid % V));
-        r[u] = buf_load16(rr, off[u], 0);  // zeros without a residual
+        r[u] = buf_ld4<ES>(rr, off[u]);  // zeros without a residual
       }
 #pragma unroll
       for (int u = 0; u < HB; ++u) {
@@ -511,27 +533,27 @@ __device__ __forceinline__ void fprop_affine_epilogue(const f32x16 (&acc)[BM / W
           o.z = fmaxf(o.z, 0.f);
           o.w = fmaxf(o.w, 0.f);
         }
-        buf_store16(yr, off[u], o);
+        buf_st4<ES>(yr, off[u], o);
       }
     }
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int ES = 4>
 __device__ __forceinline__ void fprop_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ smem,
-                                               float* __restrict__ y, const Geom& g, const FpropEpi& epi, int mt, int nt, int tid) {
+                                               void* __restrict__ y, const Geom& g, const FpropEpi& epi, int mt, int nt, int tid) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * 32;
   if (epi.scale != nullptr) {
-    fprop_affine_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
+    fprop_affine_epilogue<BM, BN, WM, WN, ES>(acc, smem, y, g, epi, mt, nt, tid);
     return;
   }
   float* const bn_partial = epi.bn_partial;
   const int MT = epi.MT;
   staged_epilogue<BM, BN, WM, WN>(acc, smem, tid, [&](int tr, int tc, float4 v) {
     const int row = mt * BM + tr;
-    if (row < g.M) *reinterpret_cast<float4*>(y + (size_t)row * g.Cout + nt * BN + tc) = v;
+    if (row < g.M) act_st4<ES>(y, ((size_t)row * g.Cout + nt * BN + tc) >> 2, v);
   });
   if (bn_partial != nullptr) {
     float cs[TN], cq[TN];
@@ -1992,10 +2014,11 @@ __device__ __forceinline__ void pl_pipeline2(int n, LoadF&& load, StoreF&& store
 }
 
 // ---- fprop ------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NBUF, int NP = 3, bool PRE = false>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_kernel(const float* __restrict__ x,
+// ES: bytes per element of x / y / the residual (4 = fp32, 2 = bf16 storage: NP = 1 only, the loader's conversion is then exact)
+template <int BM, int BN, int WM, int WN, int NBUF, int NP = 3, bool PRE = false, int ES = 4>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_kernel(const void* __restrict__ x,
                                                                                       const unsigned short* __restrict__ wp,
-                                                                                      float* __restrict__ y, Geom g, int NT, Work wk,
+                                                                                      void* __restrict__ y, Geom g, int NT, Work wk,
                                                                                       float* __restrict__ slab, FpropEpi epi) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -2016,7 +2039,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
   const int arow = tid >> 3, kg = tid & 7;
   const int brow = tid >> 2, bc = tid & 3;
   const int HoWo = g.Ho * g.Wo;
-  const int frame_bytes = g.H * g.W * g.Cin * 4;
+  static_assert(ES == 4 || (NP == 1 && !PRE), "bf16 storage: single-product arithmetic only");
+  const int frame_bytes = g.H * g.W * g.Cin * ES;
   const int plane_bytes = g.Cout * g.Ktot * 2;
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * frame_bytes, 0x00020000);
@@ -2033,7 +2057,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
     a_t[p] = n % g.T;
     a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);  // rows past M fail every bounds test
     a_wi0[p] = wo * g.stride - g.pad_w;
-    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad_w) * g.Cin * 4 + 16 * kg;
+    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad_w) * g.Cin * ES + 4 * ES * kg;
   }
   int b_base[BPP];
   const bool b_active = BN * 4 >= NTHR || tid < BN * 4;   // a 64-row weight tile is loaded by the first four waves only
@@ -2065,13 +2089,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
       pvalid[SET] = 0u;
     }
     const int cls = shift_class(chunk * BK + 4 * kg, g.fold);
-    const int koff_a = ((r * g.W + s) * g.Cin + chunk * BK) * 4;
+    const int koff_a = ((r * g.W + s) * g.Cin + chunk * BK) * ES;
     const int koff_b = kt_w * g.Cout * 64;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       const bool v = (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W &&
                      (unsigned)(a_t[p] + cls) < (unsigned)g.T;
-      ra[SET][p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB), 0);
+      ra[SET][p] = buf_ld4<ES>(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB));
       if constexpr (PRE) pvalid[SET] |= (v ? 1u : 0u) << p;
     }
 #pragma unroll
@@ -2136,16 +2160,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
     store_partial<TM, TN, NTHR>(slab, it.pslot, acc, tid);
     return;
   }
-  fprop_epilogue<BM, BN, WM, WN>(acc, smem, y, g, epi, mt, nt, tid);
+  fprop_epilogue<BM, BN, WM, WN, ES>(acc, smem, y, g, epi, mt, nt, tid);
 }
 
 // ---- dgrad ------------------------------------------------------------------------------------
 // dp = the D planes of bdv_conv_split_weights: B rows = input channels ci, contraction over (tap, co) with co contiguous.
-template <int BM, int BN, int WM, int WN, int NBUF, int NP = 3>
-__global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : (WM * WN) / 4) void conv_dgrad_pl_kernel(const float* __restrict__ dy,
+template <int BM, int BN, int WM, int WN, int NBUF, int NP = 3, int ES = 4>
+__global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : (WM * WN) / 4) void conv_dgrad_pl_kernel(const void* __restrict__ dy,
                                                                                       const unsigned short* __restrict__ dp,
-                                                                                      float* __restrict__ dx,
-                                                                                      const float* __restrict__ add_src,
+                                                                                      void* __restrict__ dx,
+                                                                                      const void* __restrict__ add_src,
                                                                                       const uint32_t* __restrict__ add_mask, Geom g,
                                                                                       int NT, Work wk, float* __restrict__ slab,
                                                                                       BnStat stat) {
@@ -2197,7 +2221,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : (WM * WN) / 4) void co
   const int HcWc = Hc * Wc;
   const int RS = g.R * g.S;
   const int plane_bytes = g.Cout * RS * g.Cin * 2;
-  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.N * g.Ho * g.Wo * g.Cout * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.N * g.Ho * g.Wo * g.Cout * ES, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)dp, 0, 3 * plane_bytes, 0x00020000);
 
   int a_base[AP], a_h[AP], a_w[AP];
@@ -2211,7 +2235,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : (WM * WN) / 4) void co
     const int hc = rem / Wc, wc = rem - hc * Wc;
     a_h[p] = ok ? hc + bh : -(1 << 20);
     a_w[p] = wc + bw;
-    a_base[p] = ((n * g.Ho + hc + bh) * g.Wo + wc + bw) * g.Cout * 4 + 16 * kg;
+    a_base[p] = ((n * g.Ho + hc + bh) * g.Wo + wc + bw) * g.Cout * ES + 4 * ES * kg;
   }
   int b_base[BPP];
   const bool b_active = BN * 4 >= NTHR || tid < BN * 4;   // a 64-row weight tile is loaded by the first four waves only
@@ -2233,12 +2257,12 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : (WM * WN) / 4) void co
   auto load = [&](auto set) __attribute__((always_inline)) {
     constexpr int SET = decltype(set)::value;
     const int tap = (r0 + ir * st) * g.S + (s0 + is * st);
-    const int koff_a = (chunk * BK - (ir * g.Wo + is) * g.Cout) * 4;
+    const int koff_a = (chunk * BK - (ir * g.Wo + is) * g.Cout) * ES;
     const int koff_b = (tap * nchunk + chunk) * g.Cin * 64;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       const bool v = (unsigned)(a_h[p] - ir) < (unsigned)g.Ho && (unsigned)(a_w[p] - is) < (unsigned)g.Wo;
-      ra[SET][p] = buf_load16(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB), 0);
+      ra[SET][p] = buf_ld4<ES>(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB));
     }
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl)
@@ -2293,7 +2317,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : (WM * WN) / 4) void co
     store_partial<TM, TN, NTHR>(slab, it.pslot, acc, tid);
     return;
   }
-  dgrad_epilogue<BM, BN, WM, WN>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
+  dgrad_epilogue<BM, BN, WM, WN, true, ES>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
     if (st == 1) return mrow;
     const int n = mrow / HcWc;
     const int rem = mrow - n * HcWc;
@@ -2348,8 +2372,8 @@ __device__ __forceinline__ bf16x8_t pl_frag_tr(const unsigned char* __restrict__
 // loads of the ones after are issued among the MFMAs of the current stage, one barrier per 16 pixels -- used for the 128 x 256 and
 // 256 x 128 tiles (0.349 -> 0.315 ms on the 256 -> 128 site, 0.181 -> 0.162 on 128 <-> 512); the 256 x 256 tile has no registers
 // left for a second set.
-template <int BM, int BN, int WM, int WN, bool INCR, int NP = 3, bool MTAP = false, int KW = 32>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int BM, int BN, int WM, int WN, bool INCR, int NP = 3, bool MTAP = false, int KW = 32, int ES = 4>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                                          float* __restrict__ slab, Geom g, int MTw, int NTw,
                                                                          int kt_per_split, const float* __restrict__ pre_scale,
                                                                          const float* __restrict__ pre_shift) {
@@ -2381,9 +2405,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int HoWo = g.Ho * g.Wo;
-  const int frame_bytes = g.H * g.W * g.Cin * 4;
+  const int frame_bytes = g.H * g.W * g.Cin * ES;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, g.N * g.st_t * frame_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.M * g.Cout * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, g.M * g.Cout * ES, 0x00020000);
 
   // A: dy rows m0 + krow, columns mt*BM + 4*c4
   int a_off[AP], a_krow[AP];
@@ -2391,7 +2415,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
   for (int p = 0; p < AP; ++p) {
     const int idx = tid + NTHR * p;
     a_krow[p] = idx / AV;
-    a_off[p] = (a_krow[p] * g.Cout + mt * BM + 4 * (idx % AV)) * 4;
+    a_off[p] = (a_krow[p] * g.Cout + mt * BM + 4 * (idx % AV)) * ES;
   }
   // B: GEMM column nt * BN + j = (tap, ci) with ci fastest; rows = input pixels of the tap
   int b_krow[BP], b_off[BP], b_cls[BP], b_r[BP], b_s[BP];
@@ -2407,7 +2431,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
     b_s[p] = rs % g.S - g.pad_w;
     // frame offset of the tap in input frames: the temporal shift's -1 / 0 / +1, or the stem's temporal tap dt - Rt / 2
     b_cls[p] = shift_class(ci, g.fold) + (MTAP ? dt - g.Rt / 2 : 0);
-    b_off[p] = ((b_r[p] * g.W + b_s[p]) * g.Cin + ci) * 4 + b_cls[p] * frame_bytes;
+    b_off[p] = ((b_r[p] * g.W + b_s[p]) * g.Cin + ci) * ES + b_cls[p] * frame_bytes;
   }
 
   if (pre) {
@@ -2429,7 +2453,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
   const int st = g.stride;
   const int d_ho = KW / g.Wo, d_wo = KW - d_ho * g.Wo;
   const int wrap_w = g.Wo * st, wrap_h = g.Ho * st;
-  const int px = g.Cin * 4;
+  const int px = g.Cin * ES;
   const int inc0 = (d_ho * st * g.W + d_wo * st) * px;
   const int inc1 = (st * g.W - wrap_w) * px;
   const int inc2 = (g.st_t * g.H * g.W - wrap_h * g.W) * px;   // to the next output frame = st_t input frames on
@@ -2458,7 +2482,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
     bvalid[SET] = 0u;
 #pragma unroll
     for (int p = 0; p < AP; ++p)  // rows past M lie past num_records: zeros
-      ra[SET][p] = buf_load16(yr, a_off[p] + m0 * g.Cout * 4, 0);
+      ra[SET][p] = buf_ld4<ES>(yr, a_off[p] + m0 * g.Cout * ES);
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
       const int m = m0 + b_krow[p];
@@ -2490,7 +2514,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const fl
       }
       const bool v = mok && (unsigned)(hi + b_r[p]) < (unsigned)g.H && (unsigned)(wi_ + b_s[p]) < (unsigned)g.W &&
                      (unsigned)(t * g.st_t + b_cls[p]) < (unsigned)(g.T * g.st_t);
-      rb[SET][p] = buf_load16(xr, off | (v ? 0 : kOOB), 0);
+      rb[SET][p] = buf_ld4<ES>(xr, off | (v ? 0 : kOOB));
       bvalid[SET] |= (v ? 1u : 0u) << p;
     }
   };
@@ -2944,6 +2968,9 @@ int pl_wgrad_form(const bdv_conv_geom* g) {
   if (g->Cout % 256 == 0 && g->Cin == 64 && RS == 1) return 3;
   if (g->Cout == 64 && g->Cin % 256 == 0 && RS == 1) return 4;
   if (g->Cout == 64 && g->Cin == 4 && c4_x3_enabled()) return 5;   // any number of taps: tiles of 64 taps (Rt * R * S of them)
+  // bf16 storage has no other kernel family to fall back to: the 64 x 64 tile (one filter tap per tile) covers what is left
+  // (R18 / R34: 64 -> 128 channels)
+  if (g->act_dtype == BDV_ACT_BF16 && g->Cout % 64 == 0 && g->Cin % 64 == 0) return 2;
   return -1;
 }
 bool pl_wgrad_ok(const bdv_conv_geom* g) { return pl_wgrad_form(g) >= 0; }
@@ -3300,19 +3327,24 @@ extern "C" int bdv_conv_fprop_pre_ok(const bdv_conv_geom* gg) {
   return pl_fprop_cfg_pre(gg) >= 0 && gg->fold == 0 ? 1 : 0;
 }
 
-extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* planes_fprop, float* y, const bdv_conv_geom* gg,
+extern "C" int bdv_conv_fprop_pl(const void* x, const float* w, const void* planes_fprop, void* y, const bdv_conv_geom* gg,
                                  float* bn_partial, const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes,
                                  int pieces, const float* pre_scale, const float* pre_shift, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_fprop_pl")) return e;
   BDV_REQUIRE(pieces == 3 || pieces == 1, "bdv_conv_fprop_pl: pieces = %d (3 or 1)", pieces);
   const bool pre = pre_scale != nullptr;
+  const bool h16 = gg->act_dtype == BDV_ACT_BF16;
+  BDV_REQUIRE_ACT(gg->act_dtype, "bdv_conv_fprop_pl");
+  if (h16)   // bf16 storage: the single-product plane kernels are the only kernels that read / write it
+    BDV_REQUIRE(pieces == 1 && !pre && planes_fprop != nullptr && pl_fprop_ok(gg, 1),
+                "bdv_conv_fprop_pl: bf16 activation storage needs pieces = 1, the weight planes, Cin %% 32 == 0 and Cout %% 64 == 0 (Cin=%d Cout=%d)", gg->Cin, gg->Cout);
   if (pre) {
     BDV_REQUIRE(pre_shift != nullptr && planes_fprop != nullptr && pieces == 3 && gg->fold == 0 && pl_fprop_cfg_pre(gg) >= 0,
                 "bdv_conv_fprop_pl: a producer BatchNorm in the loader needs the plane kernels (pieces 3, no temporal shift, Cin %% 32 == 0)");
     BDV_REQUIRE(bdv_aligned16(pre_scale) && bdv_aligned16(pre_shift), "bdv_conv_fprop_pl: pre_scale / pre_shift must be 16-byte aligned");
   }
   if (!pre && (planes_fprop == nullptr || !pl_fprop_ok(gg, pieces)))  // sites of the two-workgroups-per-CU kernels (weights from the planes too)
-    return conv_fprop_impl(x, w, y, gg, bn_partial, affine, workspace, workspace_bytes, stream, true,
+    return conv_fprop_impl((const float*)x, w, (float*)y, gg, bn_partial, affine, workspace, workspace_bytes, stream, true,
                            gg->Cin % BK == 0 && r1_planes_enabled() ? planes_fprop : nullptr);
   BDV_REQUIRE(x && y, "bdv_conv_fprop_pl: null pointer");
   FpropEpi epi = {bn_partial, 0, nullptr, nullptr, nullptr, 0, pre_scale, pre_shift};
@@ -3333,7 +3365,7 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
   g.Ktot = g.Rt * g.R * g.S * g.Cin;
   BDV_REQUIRE((int64_t)3 * g.Cout * g.Ktot * 2 < (1ll << 31), "bdv_conv_fprop_pl: weight planes exceed 2^31 bytes");
   hipStream_t s = (hipStream_t)stream;
-  const PlPlan p = plan_pl(pre ? pl_fprop_cfg_pre(gg) : pl_fprop_cfg(gg, pieces), g.M, g.Cout, g.Ktot / BK, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, true);
+  const PlPlan p = plan_pl(pre ? pl_fprop_cfg_pre(gg) : pl_fprop_cfg(gg, pieces), g.M, g.Cout, g.Ktot / BK, workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, !h16);  // (no K split with bf16 storage: the fix-up kernels are fp32)
   BDV_REQUIRE(p.cfg >= 0, "bdv_conv_fprop_pl: no tile configuration for Cout=%d", g.Cout);
   // bn_partial has one row per row tile of THIS kernel: bdv_conv_fprop_pl_stat_rows(g)
   const int blocks = p.wk.dp_tiles + p.wk.rem_tiles * p.wk.split;
@@ -3345,7 +3377,10 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
             g.W, g.Cin, g.Cout, g.R, g.stride, p.cfg, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split, p.est_us);
 #define BDV_FPROP_PL(BM_, BN_, WM_, WN_, NB_)                                                                                         \
   do {                                                                                                                                \
-    if (pre)                                                                                                                          \
+    if (h16)                                                                                                                          \
+      hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_, 1, false, 2>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y, \
+                         g, p.NT, p.wk, slab, epi);                                                                                   \
+    else if (pre)                                                                                                                     \
       hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_, 3, true>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y,  \
                          g, p.NT, p.wk, slab, epi);                                                                                   \
     else if (pieces == 1)                                                                                                             \
@@ -3357,7 +3392,7 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
     BDV_LAUNCH_CHECK("bdv_conv_fprop_pl");                                                                                            \
     if (p.wk.split > 1) {                                                                                                             \
       hipLaunchKernelGGL((conv_fprop_fixup_kernel<BM_, BN_, WM_, WN_>), dim3(p.wk.rem_tiles), dim3(64 * WM_ * WN_), 0, s,             \
-                         (const float*)slab, y, g, p.NT, p.wk, epi);                                                                  \
+                         (const float*)slab, (float*)y, g, p.NT, p.wk, epi);                                                                  \
       BDV_LAUNCH_CHECK("bdv_conv_fprop_pl(fixup)");                                                                                   \
     }                                                                                                                                 \
   } while (0)
@@ -3369,13 +3404,18 @@ extern "C" int bdv_conv_fprop_pl(const float* x, const float* w, const void* pla
   return BDV_OK;
 }
 
-extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* planes_dgrad, float* dx, const float* add_src,
+extern "C" int bdv_conv_dgrad_pl(const void* dy, const float* w, const void* planes_dgrad, void* dx, const void* add_src,
                                  const uint32_t* add_mask_src, const bdv_conv_geom* gg, const bdv_bn_stat_fuse* bn_stat,
                                  void* workspace, size_t workspace_bytes, int pieces, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_dgrad_pl")) return e;
   BDV_REQUIRE(pieces == 3 || pieces == 1, "bdv_conv_dgrad_pl: pieces = %d (3 or 1)", pieces);
+  const bool h16 = gg->act_dtype == BDV_ACT_BF16;
+  BDV_REQUIRE_ACT(gg->act_dtype, "bdv_conv_dgrad_pl");
+  if (h16)
+    BDV_REQUIRE(pieces == 1 && planes_dgrad != nullptr && pl_dgrad_ok(gg, 1),
+                "bdv_conv_dgrad_pl: bf16 activation storage needs pieces = 1, the weight planes, Cout %% 32 == 0 and Cin %% 64 == 0 (Cin=%d Cout=%d)", gg->Cin, gg->Cout);
   if (planes_dgrad == nullptr || !pl_dgrad_ok(gg, pieces))
-    return conv_dgrad_impl(dy, w, nullptr, dx, add_src, add_mask_src, gg, bn_stat, workspace, workspace_bytes, stream,
+    return conv_dgrad_impl((const float*)dy, w, nullptr, (float*)dx, (const float*)add_src, add_mask_src, gg, bn_stat, workspace, workspace_bytes, stream,
                            gg->Cout % BK == 0 && r1_planes_enabled() ? planes_dgrad : nullptr);
   BnStat stat = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
   if (bn_stat != nullptr) {
@@ -3405,7 +3445,7 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
   const int st = g.stride;
   const int Mc0 = g.N * ((g.H + st - 1) / st) * ((g.W + st - 1) / st);  // largest parity class
   PlPlan p = plan_pl(pl_dgrad_cfg(gg, pieces), st == 1 ? g.M : Mc0, g.Cin, g.Ktot / BK,
-                     workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, st == 1);
+                     workspace ? (workspace_bytes < kMaxSplitWorkspace ? workspace_bytes : kMaxSplitWorkspace) : 0, st == 1 && !h16);
   BDV_REQUIRE(p.cfg >= 0, "bdv_conv_dgrad_pl: no tile configuration for Cin=%d", g.Cin);
   if (st != 1) p.wk.dp_tiles = ((p.MT + 7) / 8) * 8 * p.NT;  // padded grid per parity class
   // the statistics partial has one row per row tile of THIS kernel (stride 2: per parity class and row tile)
@@ -3421,7 +3461,10 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
             g.W, g.Cin, g.Cout, g.R, g.stride, p.cfg, p.MT * p.NT, p.nk, p.wk.dp_tiles, p.wk.rem_tiles, p.wk.split, p.est_us);
 #define BDV_DGRAD_PL(BM_, BN_, WM_, WN_, NB_)                                                                                          \
   do {                                                                                                                                 \
-    if (pieces == 1)                                                                                                                   \
+    if (h16)                                                                                                                           \
+      hipLaunchKernelGGL((conv_dgrad_pl_kernel<BM_, BN_, WM_, WN_, NB_, 1, 2>), grid, dim3(64 * WM_ * WN_), 0, s, dy, dp, dx, add_src,  \
+                         add_mask_src, g, p.NT, p.wk, slab, stat);                                                                     \
+    else if (pieces == 1)                                                                                                              \
       hipLaunchKernelGGL((conv_dgrad_pl_kernel<BM_, BN_, WM_, WN_, NB_, 1>), grid, dim3(64 * WM_ * WN_), 0, s, dy, dp, dx, add_src,     \
                          add_mask_src, g, p.NT, p.wk, slab, stat);                                                                     \
     else                                                                                                                               \
@@ -3430,7 +3473,7 @@ extern "C" int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* pl
     BDV_LAUNCH_CHECK("bdv_conv_dgrad_pl");                                                                                             \
     if (p.wk.split > 1) {                                                                                                              \
       hipLaunchKernelGGL((conv_dgrad_fixup_kernel<BM_, BN_, WM_, WN_>), dim3(p.wk.rem_tiles), dim3(64 * WM_ * WN_), 0, s,              \
-                         (const float*)slab, dx, add_src, add_mask_src, g, p.NT, p.wk, stat);                                          \
+                         (const float*)slab, (float*)dx, (const float*)add_src, add_mask_src, g, p.NT, p.wk, stat);                                          \
       BDV_LAUNCH_CHECK("bdv_conv_dgrad_pl(fixup)");                                                                                    \
     }                                                                                                                                  \
   } while (0)
@@ -3544,7 +3587,7 @@ extern "C" int bdv_conv_wgrad_pre_ok(const bdv_conv_geom* gg) {
   return pl_wgrad_ok(gg) && gg->Cin % BK == 0 && gg->fold == 0 ? 1 : 0;
 }
 
-extern "C" int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const bdv_conv_geom* gg, void* slab, size_t slab_bytes,
+extern "C" int bdv_conv_wgrad_partial_pl(const void* dy, const void* x, const bdv_conv_geom* gg, void* slab, size_t slab_bytes,
                                          int pieces, const float* pre_scale, const float* pre_shift, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_wgrad_partial_pl")) return e;
   BDV_REQUIRE(pre_scale == nullptr || (pre_shift != nullptr && pl_wgrad_ok(gg) && gg->Cin % BK == 0 && gg->fold == 0),
@@ -3552,9 +3595,14 @@ extern "C" int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const 
   BDV_REQUIRE(pieces == 3 || pieces == 1, "bdv_conv_wgrad_partial_pl: pieces = %d (3 or 1)", pieces);
   BDV_REQUIRE(dy && x && slab, "bdv_conv_wgrad_partial_pl: null pointer");
   BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(slab), "bdv_conv_wgrad_partial_pl: pointers must be 16-byte aligned");
+  const bool h16 = gg->act_dtype == BDV_ACT_BF16;
+  BDV_REQUIRE_ACT(gg->act_dtype, "bdv_conv_wgrad_partial_pl");
+  if (h16)
+    BDV_REQUIRE(pieces == 1 && pre_scale == nullptr && pl_wgrad_ok(gg) && gg->Cin % BK == 0,
+                "bdv_conv_wgrad_partial_pl: bf16 activation storage needs pieces = 1 and the plane kernel (Cin %% 32 == 0; Cin=%d Cout=%d)", gg->Cin, gg->Cout);
   if (!pl_wgrad_ok(gg)) {
     int splits = 0;
-    return wgrad_partial("bdv_conv_wgrad_partial_pl", dy, x, gg, slab, slab_bytes, (hipStream_t)stream, &splits, pieces == 3);
+    return wgrad_partial("bdv_conv_wgrad_partial_pl", (const float*)dy, (const float*)x, gg, slab, slab_bytes, (hipStream_t)stream, &splits, pieces == 3);
   }
   const WgradPlPlan p = plan_wgrad_pl(gg);
   const size_t need = (size_t)p.splits * gg->Cout * (gg->Rt > 1 ? gg->Rt : 1) * gg->R * gg->S * gg->Cin * sizeof(float);
@@ -3571,15 +3619,17 @@ extern "C" int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const 
     fprintf(stderr, "[bdv plan] wgrad_pl %dx%d Cin %d Cout %d k%d s%d: %dx%d tiles %d -> splits %d x %d k-iters\n", gg->H, gg->W, gg->Cin,
             gg->Cout, gg->R, gg->stride, p.BM, p.BN, p.MTw * p.NTw, p.splits, p.kt_per_split);
   const bool incr = g.Ho * g.Wo > BK && BK / g.Wo + 1 <= g.Ho;
-#define BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, INCR_, NP_, MTAP_, KW_)                                                                \
-  hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, WM_, WN_, INCR_, NP_, MTAP_, KW_>), grid, dim3(64 * WM_ * WN_), 0, s, dy, x, \
+#define BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, INCR_, NP_, MTAP_, KW_, ES_)                                                                \
+  hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, WM_, WN_, INCR_, NP_, MTAP_, KW_, ES_>), grid, dim3(64 * WM_ * WN_), 0, s, dy, x, \
                      (float*)slab, g, p.MTw, p.NTw, p.kt_per_split, pre_scale, pre_shift)
 #define BDV_WGRAD_PL(BM_, BN_, WM_, WN_, MTAP_, KW_)                                                                             \
   do {                                                                                                                           \
-    if (incr && pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 3, MTAP_, KW_);                                             \
-    else if (pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 3, MTAP_, KW_);                                               \
-    else if (incr) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 1, MTAP_, KW_);                                                       \
-    else BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 1, MTAP_, KW_);                                                                \
+    if (h16 && incr) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 1, MTAP_, KW_, 2);                                                  \
+    else if (h16) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 1, MTAP_, KW_, 2);                                                    \
+    else if (incr && pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 3, MTAP_, KW_, 4);                                     \
+    else if (pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 3, MTAP_, KW_, 4);                                            \
+    else if (incr) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 1, MTAP_, KW_, 4);                                                    \
+    else BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 1, MTAP_, KW_, 4);                                                             \
   } while (0)
   const bool two_stage = wgrad_two_stage();
   if (p.form == 1) BDV_WGRAD_PL(64, 192, 2, 2, true, 32);

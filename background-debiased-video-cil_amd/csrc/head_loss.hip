@@ -462,13 +462,14 @@ __global__ __launch_bounds__(256) void topk_acc_kernel(const float* __restrict__
 // ---- feature-distillation MSE ---------------------------------------------------------------
 constexpr int RED_BLOCKS = 1024;
 
-__global__ __launch_bounds__(256) void sqdiff_partial_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+template <int ES = 4>
+__global__ __launch_bounds__(256) void sqdiff_partial_kernel(const void* __restrict__ a, const void* __restrict__ b,
                                                               float* __restrict__ partial, int64_t n4) {
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float s = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n4; i += (int64_t)gridDim.x * 256) {
-    const float4 x = a[i], y = b[i];
+    const float4 x = act_ld4<ES>(a, i), y = act_ld4<ES>(b, i);
     const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
     s += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
   }
@@ -486,13 +487,14 @@ __global__ void mse_finalize_kernel(const float* __restrict__ partial, int nb, d
   if (lane == 0) out[0] = (float)(s * inv_numel);
 }
 
-__global__ __launch_bounds__(256) void kd_mse_bwd_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
-                                                          const float* __restrict__ gdev, float ghost, float4* __restrict__ da,
+template <int ES = 4>
+__global__ __launch_bounds__(256) void kd_mse_bwd_kernel(const void* __restrict__ a, const void* __restrict__ b,
+                                                          const float* __restrict__ gdev, float ghost, void* __restrict__ da,
                                                           int64_t n4) {
   const float c = ghost * (gdev != nullptr ? gdev[0] : 1.f);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const float4 x = a[i], y = b[i];
-    da[i] = make_float4(c * (x.x - y.x), c * (x.y - y.y), c * (x.z - y.z), c * (x.w - y.w));
+    const float4 x = act_ld4<ES>(a, i), y = act_ld4<ES>(b, i);
+    act_st4<ES>(da, i, make_float4(c * (x.x - y.x), c * (x.y - y.y), c * (x.z - y.z), c * (x.w - y.w)));
   }
 }
 
@@ -631,8 +633,9 @@ extern "C" int bdv_topk_acc(const float* score, const int64_t* labels, float* ac
 
 extern "C" size_t bdv_reduce_workspace_bytes(void) { return RED_BLOCKS * sizeof(float); }
 
-extern "C" int bdv_kd_mse_fwd(const float* cur, const float* prev, float* mse, int64_t numel, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+extern "C" int bdv_kd_mse_fwd(const void* cur, const void* prev, float* mse, int64_t numel, void* workspace,
+                              size_t workspace_bytes, int act_dtype, void* stream) {
+  BDV_REQUIRE_ACT(act_dtype, "bdv_kd_mse_fwd");
   BDV_REQUIRE(cur && prev && mse && workspace && numel > 0 && numel % 4 == 0, "bdv_kd_mse_fwd: bad argument");
   BDV_REQUIRE(bdv_aligned16(cur) && bdv_aligned16(prev), "bdv_kd_mse_fwd: alignment");
   if (workspace_bytes < bdv_reduce_workspace_bytes()) {
@@ -642,23 +645,24 @@ extern "C" int bdv_kd_mse_fwd(const float* cur, const float* prev, float* mse, i
   const int64_t n4 = numel / 4;
   int nb = (int)((n4 + 255) / 256);
   if (nb > RED_BLOCKS) nb = RED_BLOCKS;
-  hipLaunchKernelGGL(sqdiff_partial_kernel, dim3(nb), dim3(256), 0, HL_STREAM, (const float4*)cur, (const float4*)prev,
-                     (float*)workspace, n4);
+  BDV_ACT_SWITCH(act_dtype, ES, hipLaunchKernelGGL((sqdiff_partial_kernel<ES>), dim3(nb), dim3(256), 0, HL_STREAM, cur, prev,
+                     (float*)workspace, n4));
   BDV_LAUNCH_CHECK("bdv_kd_mse_fwd(partial)");
   hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, HL_STREAM, (const float*)workspace, nb, 1.0 / (double)numel, mse);
   BDV_LAUNCH_CHECK("bdv_kd_mse_fwd(finalize)");
   return BDV_OK;
 }
 
-extern "C" int bdv_kd_mse_bwd(const float* cur, const float* prev, const float* gscale_dev, float gscale_host, float* dcur,
-                              int64_t numel, void* stream) {
+extern "C" int bdv_kd_mse_bwd(const void* cur, const void* prev, const float* gscale_dev, float gscale_host, void* dcur,
+                              int64_t numel, int act_dtype, void* stream) {
+  BDV_REQUIRE_ACT(act_dtype, "bdv_kd_mse_bwd");
   BDV_REQUIRE(cur && prev && dcur && numel > 0 && numel % 4 == 0, "bdv_kd_mse_bwd: bad argument");
   BDV_REQUIRE(bdv_aligned16(cur) && bdv_aligned16(prev) && bdv_aligned16(dcur), "bdv_kd_mse_bwd: alignment");
   const int64_t n4 = numel / 4;
   int64_t nb = (n4 + 255) / 256;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(kd_mse_bwd_kernel, dim3((int)nb), dim3(256), 0, HL_STREAM, (const float4*)cur, (const float4*)prev, gscale_dev,
-                     gscale_host * 2.f / (float)numel, (float4*)dcur, n4);
+  BDV_ACT_SWITCH(act_dtype, ES, hipLaunchKernelGGL((kd_mse_bwd_kernel<ES>), dim3((int)nb), dim3(256), 0, HL_STREAM, cur, prev, gscale_dev,
+                     gscale_host * 2.f / (float)numel, dcur, n4));
   BDV_LAUNCH_CHECK("bdv_kd_mse_bwd");
   return BDV_OK;
 }

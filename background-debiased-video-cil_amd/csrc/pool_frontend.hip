@@ -18,7 +18,8 @@ __global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float* __rest
 
 // MaxPool2d(3, 2, 1) NHWC; thread = (output pixel, 4 channels).  First maximum in (r,s) scan order wins.
 // grid.y = (frame, output row): the only division left per thread is the small 32-bit one by the channel-vector count.
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ out,
+template <int ESO = 4>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float4* __restrict__ x, void* __restrict__ out,
                                                            uchar4* __restrict__ idx, int N, int H, int W, int CV, int Ho, int Wo) {
   for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
     const int n = row / Ho, ho = row - n * Ho;
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float4* __restri
           if (v.w > m.w || mi.w == 255) { m.w = v.w; mi.w = t; }
         }
       }
-      out[orow + i] = m;
+      act_st4<ESO>(out, orow + i, m);
       idx[orow + i] = mi;
     }
   }
@@ -55,8 +56,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float4* __restri
 // BatchNorm backward).  thread = (pooled pixel, 4 channels); the thread also owns the 2x2 input pixels
 // (2ho..2ho+1, 2wo..2wo+1), which lie inside its window, for the mask: 8 neighbouring lanes hold the 32 channels of one
 // pixel and merge their nibbles into the mask word.
+template <int ESO = 4>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float4* __restrict__ y, const float4* __restrict__ scale,
-                                                                   const float4* __restrict__ shift, float4* __restrict__ out,
+                                                                   const float4* __restrict__ shift, void* __restrict__ out,
                                                                    uchar4* __restrict__ idx, uint32_t* __restrict__ mask, int N,
                                                                    int H, int W, int CV, int Ho, int Wo) {
   for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float4* 
             nib[r - 1][s - 1] = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
         }
       }
-      out[orow + i] = m;
+      act_st4<ESO>(out, orow + i, m);
       idx[orow + i] = mi;
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float4* 
 
 // Backward as a gather without divergence (pool_bwd_gather2x2 in common.h): a thread owns the 2x2 input block
 // (2i..2i+1, 2j..2j+1) x 4 channels and loads each of the four windows that cover it once.  grid.y = (frame, block row i).
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restrict__ dout, const uchar4* __restrict__ idx,
+template <int ESD = 4>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* __restrict__ dout, const uchar4* __restrict__ idx,
                                                            float4* __restrict__ dx, int N, int H, int W, int CV, int Ho, int Wo) {
   for (int row = blockIdx.y; row < N * Ho; row += gridDim.y) {
     const int n = row / Ho, i = row - n * Ho;
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restri
       const int j = q / CV, c4 = q - j * CV;
       const bool right = j + 1 < Wo, w1ok = 2 * j + 1 < W;
       float4 g[4];
-      pool_bwd_gather2x2(dout, idx, obase + (i * Wo + j) * CV + c4, CV, Wo, right, down, g);
+      pool_bwd_gather2x2<ESD>(dout, idx, obase + (i * Wo + j) * CV + c4, CV, Wo, right, down, g);
       const int64_t p00 = ibase + ((2 * i) * W + 2 * j) * CV + c4;
       dx[p00] = g[0];
       if (w1ok) dx[p00 + CV] = g[1];
@@ -134,7 +137,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restri
 }
 
 // [N][HW][C] -> [N][C]
-__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ out, int N, int HW,
+template <int ES = 4>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const void* __restrict__ x, float4* __restrict__ out, int N, int HW,
                                                            int CV) {
   const int64_t total = (int64_t)N * CV;
   const float inv = 1.f / (float)HW;
@@ -143,14 +147,15 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float4* __restri
     const int64_t n = i / CV;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int p = 0; p < HW; ++p) {
-      const float4 v = x[(n * HW + p) * CV + c4];
+      const float4 v = act_ld4<ES>(x, (n * HW + p) * CV + c4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     out[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
   }
 }
 
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float4* __restrict__ dout, float4* __restrict__ dx, int N, int HW,
+template <int ES = 4>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float4* __restrict__ dout, void* __restrict__ dx, int N, int HW,
                                                            int CV) {
   const int64_t total = (int64_t)N * HW * CV;
   const float inv = 1.f / (float)HW;
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float4* __restri
     const int c4 = (int)(i % CV);
     const int64_t n = i / ((int64_t)HW * CV);
     const float4 d = dout[n * CV + c4];
-    dx[i] = make_float4(d.x * inv, d.y * inv, d.z * inv, d.w * inv);
+    act_st4<ES>(dx, i, make_float4(d.x * inv, d.y * inv, d.z * inv, d.w * inv));
   }
 }
 
@@ -333,20 +338,22 @@ extern "C" int bdv_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int 
   return BDV_OK;
 }
 
-extern "C" int bdv_maxpool_fwd(const float* x, float* out, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+extern "C" int bdv_maxpool_fwd(const float* x, void* out, uint8_t* idx, int N, int H, int W, int C, int out_dtype, void* stream) {
+  BDV_REQUIRE_ACT(out_dtype, "bdv_maxpool_fwd");
   BDV_REQUIRE(x && out && idx && N > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, "bdv_maxpool_fwd: bad argument");
   BDV_REQUIRE(bdv_aligned16(x) && bdv_aligned16(out) && (((uintptr_t)idx) & 3) == 0, "bdv_maxpool_fwd: alignment");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   BDV_REQUIRE((int64_t)H * W * (C / 4) < (1ll << 31) && (int64_t)N * Ho < (1ll << 31), "bdv_maxpool_fwd: frame or batch too large");
   const int rowv = Wo * (C / 4);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((rowv + 255) / 256, N * Ho < 65535 ? N * Ho : 65535), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
-                     (float4*)out, (uchar4*)idx, N, H, W, C / 4, Ho, Wo);
+  BDV_ACT_SWITCH(out_dtype, ES, hipLaunchKernelGGL((maxpool_fwd_kernel<ES>), dim3((rowv + 255) / 256, N * Ho < 65535 ? N * Ho : 65535), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                     out, (uchar4*)idx, N, H, W, C / 4, Ho, Wo));
   BDV_LAUNCH_CHECK("bdv_maxpool_fwd");
   return BDV_OK;
 }
 
-extern "C" int bdv_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, uint8_t* idx,
-                                       uint32_t* relu_mask, int N, int H, int W, int C, void* stream) {
+extern "C" int bdv_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shift, void* out, uint8_t* idx,
+                                       uint32_t* relu_mask, int N, int H, int W, int C, int out_dtype, void* stream) {
+  BDV_REQUIRE_ACT(out_dtype, "bdv_bn_relu_maxpool_fwd");
   BDV_REQUIRE(y && scale && shift && out && idx && relu_mask && N > 0 && H > 1 && W > 1 && C > 0 && C % 32 == 0,
               "bdv_bn_relu_maxpool_fwd: bad argument (C must be a multiple of 32)");
   BDV_REQUIRE(bdv_aligned16(y) && bdv_aligned16(scale) && bdv_aligned16(shift) && bdv_aligned16(out) &&
@@ -354,41 +361,44 @@ extern "C" int bdv_bn_relu_maxpool_fwd(const float* y, const float* scale, const
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   BDV_REQUIRE((int64_t)H * W * (C / 4) < (1ll << 31) && (int64_t)N * Ho < (1ll << 31), "bdv_bn_relu_maxpool_fwd: too large");
   const int rowv = Wo * (C / 4);
-  hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3((rowv + 255) / 256, N * Ho < 65535 ? N * Ho : 65535), dim3(256), 0,
-                     (hipStream_t)stream, (const float4*)y, (const float4*)scale, (const float4*)shift, (float4*)out, (uchar4*)idx,
-                     relu_mask, N, H, W, C / 4, Ho, Wo);
+  BDV_ACT_SWITCH(out_dtype, ES, hipLaunchKernelGGL((bn_relu_maxpool_fwd_kernel<ES>), dim3((rowv + 255) / 256, N * Ho < 65535 ? N * Ho : 65535), dim3(256), 0,
+                     (hipStream_t)stream, (const float4*)y, (const float4*)scale, (const float4*)shift, out, (uchar4*)idx,
+                     relu_mask, N, H, W, C / 4, Ho, Wo));
   BDV_LAUNCH_CHECK("bdv_bn_relu_maxpool_fwd");
   return BDV_OK;
 }
 
-extern "C" int bdv_maxpool_bwd(const float* dout, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream) {
+extern "C" int bdv_maxpool_bwd(const void* dout, const uint8_t* idx, float* dx, int N, int H, int W, int C, int dout_dtype, void* stream) {
+  BDV_REQUIRE_ACT(dout_dtype, "bdv_maxpool_bwd");
   BDV_REQUIRE(dout && dx && idx && N > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, "bdv_maxpool_bwd: bad argument");
   BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(dx) && (((uintptr_t)idx) & 3) == 0, "bdv_maxpool_bwd: alignment");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   BDV_REQUIRE((int64_t)Ho * Wo * (C / 4) < (1ll << 31) && (int64_t)N * H < (1ll << 31), "bdv_maxpool_bwd: frame or batch too large");
   const int rowv = Wo * (C / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((rowv + 255) / 256, N * Ho < 65535 ? N * Ho : 65535), dim3(256), 0, (hipStream_t)stream, (const float4*)dout,
-                     (const uchar4*)idx, (float4*)dx, N, H, W, C / 4, Ho, Wo);
+  BDV_ACT_SWITCH(dout_dtype, ES, hipLaunchKernelGGL((maxpool_bwd_kernel<ES>), dim3((rowv + 255) / 256, N * Ho < 65535 ? N * Ho : 65535), dim3(256), 0, (hipStream_t)stream, dout,
+                     (const uchar4*)idx, (float4*)dx, N, H, W, C / 4, Ho, Wo));
   BDV_LAUNCH_CHECK("bdv_maxpool_bwd");
   return BDV_OK;
 }
 
-extern "C" int bdv_avgpool_fwd(const float* x, float* out, int N, int HW, int C, void* stream) {
+extern "C" int bdv_avgpool_fwd(const void* x, float* out, int N, int HW, int C, int act_dtype, void* stream) {
+  BDV_REQUIRE_ACT(act_dtype, "bdv_avgpool_fwd");
   BDV_REQUIRE(x && out && N > 0 && HW > 0 && C > 0 && C % 4 == 0, "bdv_avgpool_fwd: bad argument");
   BDV_REQUIRE(bdv_aligned16(x) && bdv_aligned16(out), "bdv_avgpool_fwd: alignment");
   const int64_t total = (int64_t)N * (C / 4);
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)out, N,
-                     HW, C / 4);
+  BDV_ACT_SWITCH(act_dtype, ES, hipLaunchKernelGGL((avgpool_fwd_kernel<ES>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, (float4*)out, N,
+                     HW, C / 4));
   BDV_LAUNCH_CHECK("bdv_avgpool_fwd");
   return BDV_OK;
 }
 
-extern "C" int bdv_avgpool_bwd(const float* dout, float* dx, int N, int HW, int C, void* stream) {
+extern "C" int bdv_avgpool_bwd(const float* dout, void* dx, int N, int HW, int C, int act_dtype, void* stream) {
+  BDV_REQUIRE_ACT(act_dtype, "bdv_avgpool_bwd");
   BDV_REQUIRE(dout && dx && N > 0 && HW > 0 && C > 0 && C % 4 == 0, "bdv_avgpool_bwd: bad argument");
   BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(dx), "bdv_avgpool_bwd: alignment");
   const int64_t total = (int64_t)N * HW * (C / 4);
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout, (float4*)dx,
-                     N, HW, C / 4);
+  BDV_ACT_SWITCH(act_dtype, ES, hipLaunchKernelGGL((avgpool_bwd_kernel<ES>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout, dx,
+                     N, HW, C / 4));
   BDV_LAUNCH_CHECK("bdv_avgpool_bwd");
   return BDV_OK;
 }

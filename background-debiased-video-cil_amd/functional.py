@@ -31,8 +31,20 @@ from . import kernels as K
 # ``join_side_stream`` must run before gradients are consumed (FusedSGD.step / clip / GradAllReducer / StemFn.backward do it).
 # Measured on one box, alternating runs (profiles/r02_side_stream.txt): 535.1 / 535.0 clips/s without, 551.5 / 550.5 with.
 # BDVCIL_WGRAD_SIDE_STREAM=0 puts everything back on one stream (one batched split-K reduction per stage then).
+import collections as _collections
 import os as _os
-_SIDE = {'enabled': _os.environ.get('BDVCIL_WGRAD_SIDE_STREAM', '1') != '0', 'streams': {}, 'pending': {}}
+_SIDE = {'enabled': _os.environ.get('BDVCIL_WGRAD_SIDE_STREAM', '1') != '0', 'streams': {}, 'pending': {}, 'held': {}}
+# Lifetime of the operands of a weight gradient running on the side stream.  torch's record_stream() defers the release of a
+# block until the side stream's work at release time has finished; the host enqueues a whole step ahead of the device, so none of
+# those blocks was ever reusable inside a step and the caching allocator went back to hipMalloc for every gradient and
+# activation tensor: 115 GB reserved for 24 GB allocated at batch 32, 225 GB for 46 GB at batch 64 -- where steps then ran
+# 1.3 - 2.5 x slower in some processes (gpurun_out/lag*.log: 94 ms against 70 ms per step).  Instead the operands stay referenced
+# in a FIFO until the main stream has waited for the side stream (join_side_stream: the end of the backward pass, or a gradient
+# bucket becoming ready), after which they return to the pool in plain stream order: 46 GB reserved at batch 32, no extra
+# synchronisation, step time level or better (profiles/r02_ab_streams.txt).  BDVCIL_SIDE_LAG bounds the FIFO: the main stream
+# waits for the weight gradient that many launches back before dropping its operands (64 = never inside a ResNet-50 step;
+# smaller values trade 1 % of step time for a few GB); 0 = record_stream().
+SIDE_LAG = int(_os.environ.get('BDVCIL_SIDE_LAG', '64'))
 
 
 # BatchNorm-backward statistics of a unit taken in the epilogue of the dgrad that produces its output gradient
@@ -86,6 +98,9 @@ def join_side_stream(device=None):
         if device is None or (device.index if device.index is not None else torch.cuda.current_device()) == idx:
             torch.cuda.current_stream(idx).wait_event(ev)
             del _SIDE['pending'][idx]
+            held = _SIDE['held'].get(idx)
+            if held:
+                held.clear()        # the event is the side stream's latest: the current stream is now behind all of its work
 
 
 class wgrad_batch:
@@ -153,8 +168,15 @@ def wgrad_overlapped(dy: torch.Tensor, inp: torch.Tensor, geom, pre_bn=None) -> 
             K.conv_wgrad(dy, inp, geom, dw=dw, beta=0.0, ws_tag='wgrad_side', pre_bn=pre_bn)
         done = torch.cuda.Event()
         done.record(side)
-    for t in (dy, inp, dw):
-        t.record_stream(side)
+    if SIDE_LAG > 0:
+        held = _SIDE['held'].setdefault(idx, _collections.deque())
+        held.append((done, (dy, inp)))
+        while len(held) > SIDE_LAG:
+            ev, _ = held.popleft()
+            main.wait_event(ev)     # (long finished: the side stream runs beside the main chain, not behind it)
+    else:
+        for t in (dy, inp, dw):
+            t.record_stream(side)
     _SIDE['pending'][idx] = done
     return dw
 
@@ -294,7 +316,7 @@ class StemFn(torch.autograd.Function):
         if training:
             y, mean, invstd, scale, shift = _conv_bn_forward(x4, w4, g, bn, gamma, beta, training)
             # BN apply + ReLU + max-pool + ReLU sign mask in one pass; the activation itself is never materialised
-            p, idx, mask = K.bn_relu_maxpool_fwd(y, scale, shift)
+            p, idx, mask = K.bn_relu_maxpool_fwd(y, scale, shift, out_dtype=K.ACT_DTYPE)
             if RELU_MASK_TAP is not None:
                 RELU_MASK_TAP.append((tuple(y.shape), mask))
             if POOL_IDX_TAP is not None:
@@ -302,7 +324,7 @@ class StemFn(torch.autograd.Function):
             a_shape = tuple(y.shape)
         else:
             a = _conv_bn_eval(x4, w4, g, bn, gamma, beta, None, True)
-            p, idx = K.maxpool_fwd(a)
+            p, idx = K.maxpool_fwd(a, out_dtype=K.ACT_DTYPE)
             a_shape = tuple(a.shape)
             y = mask = mean = invstd = None
         ctx.g = g
@@ -619,6 +641,7 @@ class AvgPoolFn(torch.autograd.Function):
     def forward(ctx, x_nchw):
         x = nchw_view_to_nhwc(x_nchw)
         ctx.in_shape = tuple(x.shape)
+        ctx.in_dtype = x.dtype          # bf16 storage ends here: the pooled features and everything after them are fp32
         return K.avgpool_fwd(x).view(x.shape[0], x.shape[3], 1, 1)
 
     @staticmethod
@@ -626,7 +649,7 @@ class AvgPoolFn(torch.autograd.Function):
         N, H, W, C = ctx.in_shape
         d = dout.reshape(N, C)
         d = d if d.is_contiguous() else d.contiguous()
-        return nhwc_to_nchw_view(K.avgpool_bwd(d, ctx.in_shape))
+        return nhwc_to_nchw_view(K.avgpool_bwd(d, ctx.in_shape, ctx.in_dtype))
 
 
 class DropoutFn(torch.autograd.Function):

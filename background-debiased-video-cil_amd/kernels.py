@@ -38,19 +38,41 @@ def _chk(t: torch.Tensor, shape: Optional[Sequence[int]] = None, dtype=torch.flo
     return t
 
 
+ACT_DTYPE = torch.float32       # storage type of activations / their gradients: torch.float32, or torch.bfloat16 ('bf16' arithmetic)
+
+
+def _act_code(t: torch.Tensor) -> int:
+    """BDV_ACT_F32 (0) | BDV_ACT_BF16 (1) of an activation tensor."""
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def _chk_act(t: torch.Tensor, shape=None, name='tensor', like: Optional[torch.Tensor] = None):
+    """An activation operand: fp32, or bf16 in the bf16-storage mode; ``like``: must have that tensor's dtype."""
+    if isinstance(t, torch.Tensor) and t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f'{name}: dtype {t.dtype}, expected torch.float32 or torch.bfloat16')
+    if like is not None and isinstance(t, torch.Tensor) and t.dtype != like.dtype:
+        raise TypeError(f'{name}: dtype {t.dtype} differs from the other activation operand ({like.dtype})')
+    return _chk(t, shape, dtype=t.dtype if isinstance(t, torch.Tensor) else torch.float32, name=name)
+
+
 def _chk_conv(t: torch.Tensor, shape, g, name):
     """Operand check of a convolution.  A geometry marked ``frames_view`` (a k x 1 temporal convolution described on the
     [B][T][H*W][C] view) takes the usual [B*T][H][W][C] tensors of the same storage: element count and channel count must
     agree, the kernel only sees the pointer."""
+    if isinstance(t, torch.Tensor) and t.dtype == torch.bfloat16:
+        if g.act_dtype != 1:
+            raise TypeError(f'{name}: bf16 tensor in an fp32 convolution call (operands of one call share the storage type)')
+    elif g.act_dtype != 0:
+        raise TypeError(f'{name}: dtype {getattr(t, "dtype", None)} in a bf16-storage convolution call')
     if getattr(g, 'frames_view', False):
-        _chk(t, None, name=name)
+        _chk(t, None, dtype=t.dtype, name=name)
         n = 1
         for d in shape:
             n *= d
         if t.numel() != n or t.shape[-1] != shape[-1]:
             raise ValueError(f'{name}: shape {tuple(t.shape)} is not a view of {tuple(shape)}')
         return t
-    return _chk(t, shape, name=name)
+    return _chk(t, shape, dtype=torch.bfloat16 if g.act_dtype == 1 else torch.float32, name=name)
 
 
 def workspace(nbytes: int, device, tag='ws') -> torch.Tensor:
@@ -123,15 +145,20 @@ PIECES = 3      # 3: fp32-level products from three bf16 pieces per operand; 1: 
 
 
 def set_conv_arith(mode: str):
-    """'bf16x3' (default), 'f32mfma', or the reduced-precision 'bf16x1' (BASELINE config 5: operands rounded to bf16, one MFMA
-    product, fp32 accumulate and tensors) for fprop, dgrad and wgrad at once; returns the previous (fprop, dgrad, wgrad) flags.
+    """'bf16x3' (default), 'f32mfma', or the reduced-precision modes of BASELINE config 5: 'bf16x1' (operands rounded to bf16, one
+    MFMA product, fp32 accumulate, fp32 tensors) and 'bf16' (the same arithmetic with activations and their gradients STORED as
+    bf16 between the stem's max-pool and the average pool; fp32 statistics, weights and weight gradients) for fprop, dgrad and
+    wgrad at once; returns the previous (fprop, dgrad, wgrad) flags.
     Leaving 'bf16x1' needs another ``set_conv_arith`` call (the flags alone do not restore ``PIECES``)."""
-    global FPROP_X3, DGRAD_X3, WGRAD_X3, PIECES
-    if mode not in ('bf16x3', 'f32mfma', 'bf16x1'):
-        raise ValueError(f"set_conv_arith: unknown mode {mode!r} ('bf16x3' | 'f32mfma' | 'bf16x1')")
+    global FPROP_X3, DGRAD_X3, WGRAD_X3, PIECES, ACT_DTYPE
+    if mode not in ('bf16x3', 'f32mfma', 'bf16x1', 'bf16'):
+        raise ValueError(f"set_conv_arith: unknown mode {mode!r} ('bf16x3' | 'f32mfma' | 'bf16x1' | 'bf16')")
     prev = (FPROP_X3, DGRAD_X3, WGRAD_X3)
     FPROP_X3 = DGRAD_X3 = WGRAD_X3 = (mode != 'f32mfma')
-    PIECES = 1 if mode == 'bf16x1' else 3
+    PIECES = 1 if mode in ('bf16x1', 'bf16') else 3
+    # 'bf16': the bf16x1 arithmetic on bf16-STORED activations and gradients (BDV_ACT_BF16) from the stem's max-pool to the average
+    # pool; the tensors the model creates from here on carry the type, every kernel follows the dtype of what it is given
+    ACT_DTYPE = torch.bfloat16 if mode == 'bf16' else torch.float32
     return prev
 
 
@@ -265,14 +292,17 @@ def conv_fprop(x: torch.Tensor, w: torch.Tensor, g: ConvGeom, out: Optional[torc
     y = relu?(conv * scale + shift (+ residual)).
     ``pre_bn = (scale, shift)``: x is the RAW output of the producing conv; its train-mode BatchNorm + ReLU is applied in the
     loader (``fprop_pre_ok(g)``), so no apply pass / activation / mask is needed for this consumer."""
+    g.act_dtype = _act_code(x)
     _chk_conv(x, (_in_frames(g), g.H, g.W, g.Cin), g, 'x')
     _chk(w, (g.Cout, _taps_r(g), g.S, g.Cin), name='w')
-    y = out if out is not None else torch.empty((g.N, g.Ho, g.Wo, g.Cout), dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty((g.N, g.Ho, g.Wo, g.Cout), dtype=x.dtype, device=x.device)
     _chk_conv(y, (g.N, g.Ho, g.Wo, g.Cout), g, 'y')
     ws = _conv_ws(g, 0, x.device, ws_tag)
     part = aff = None
     use_x3 = FPROP_X3 if x3 is None else x3
     use_pl = bool(use_x3 and USE_PL and lib().bdv_conv_uses_planes(ctypes.byref(g), 0, PIECES))
+    if g.act_dtype == 1 and not (use_pl and PIECES == 1):
+        raise ValueError("conv_fprop: bf16 tensors need set_conv_arith('bf16') and a geometry of the plane kernels (Cin % 32 == 0, Cout % 64 == 0)")
     if pre_bn is not None:
         if not (use_x3 and USE_PL and PIECES == 3 and lib().bdv_conv_fprop_pre_ok(ctypes.byref(g))):
             raise ValueError('conv_fprop: pre_bn needs the bf16-piece plane kernels for this geometry (fprop_pre_ok)')
@@ -316,9 +346,10 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
     """``bn_stats = (y, relu_mask | None, mean, invstd)`` of the conv unit whose output gradient this dgrad produces:
     the BatchNorm-backward statistics are then taken in the epilogue and ``(dx, partial)`` is returned; pass ``partial``
     to ``bn_backward(stat_partial=...)``.  Stride 2 needs a filter that reaches every input pixel (R, S >= 2)."""
+    g.act_dtype = _act_code(dy)
     _chk_conv(dy, (g.N, g.Ho, g.Wo, g.Cout), g, 'dy')
     _chk(w, (g.Cout, g.R, g.S, g.Cin), name='w')
-    dx = out if out is not None else torch.empty((g.N, g.H, g.W, g.Cin), dtype=torch.float32, device=dy.device)
+    dx = out if out is not None else torch.empty((g.N, g.H, g.W, g.Cin), dtype=dy.dtype, device=dy.device)
     _chk_conv(dx, (g.N, g.H, g.W, g.Cin), g, 'dx')
     if add_src is not None:
         _chk_conv(add_src, (g.N, g.H, g.W, g.Cin), g, 'add_src')
@@ -329,6 +360,8 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
     fuse = partial = None
     use_x3 = (DGRAD_X3 if x3 is None else x3) and g.Cin % 64 == 0
     use_pl = bool(use_x3 and USE_PL and lib().bdv_conv_uses_planes(ctypes.byref(g), 1, PIECES))
+    if g.act_dtype == 1 and not (use_pl and PIECES == 1):
+        raise ValueError("conv_dgrad: bf16 tensors need set_conv_arith('bf16') and a geometry of the plane kernels (Cout % 32 == 0, Cin % 64 == 0)")
     relu_affine = None
     if bn_stats is not None:
         if len(bn_stats) == 5:      # (y, None, mean, invstd, (scale, shift)): the unit's ReLU sign is derived from y
@@ -373,6 +406,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, g: ConvGeom, add_src: Optional
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, dw: Optional[torch.Tensor] = None,
                beta: float = 0.0, ws_tag: str = 'wgrad', x3: Optional[bool] = None, pre_bn=None) -> torch.Tensor:
     """dw = beta * dw + dy^T (*) x in one call (split-K main kernel + fixed-order reduction)."""
+    g.act_dtype = _act_code(dy)
     _chk_conv(dy, (g.N, g.Ho, g.Wo, g.Cout), g, 'dy')
     _chk_conv(x, (_in_frames(g), g.H, g.W, g.Cin), g, 'x')
     if dw is None:
@@ -448,11 +482,11 @@ def bn_apply(y, scale, shift, res=None, relu=True, out=None, want_mask=False, re
     ``res_affine = (scale, shift)``: the residual is a raw conv output and gets its own BatchNorm here."""
     C = y.shape[-1]
     M = y.numel() // C
-    _chk(y, name='y')
+    _chk_act(y, name='y')
     _chk(scale, (C,), name='scale')
     _chk(shift, (C,), name='shift')
     if res is not None:
-        _chk(res, tuple(y.shape), name='res')
+        _chk_act(res, tuple(y.shape), name='res', like=y)
     rs = rb = None
     if res_affine is not None:
         if res is None:
@@ -461,14 +495,14 @@ def bn_apply(y, scale, shift, res=None, relu=True, out=None, want_mask=False, re
         _chk(rs, (C,), name='res_scale')
         _chk(rb, (C,), name='res_shift')
     o = out if out is not None else torch.empty_like(y)
-    _chk(o, tuple(y.shape), name='out')
+    _chk_act(o, tuple(y.shape), name='out', like=y)
     mask = None
     if want_mask:
         if not relu or C % 32 != 0:
             raise ValueError('bn_apply: a ReLU mask needs relu=True and C % 32 == 0')
         mask = torch.empty(y.numel() // 32, dtype=torch.int32, device=y.device)
     check(lib().bdv_bn_apply(_p(y), _p(scale), _p(shift), _p(res), _p(rs), _p(rb), _p(o), _p(mask), M, C, int(bool(relu)),
-                             _stream()), 'bdv_bn_apply')
+                             _act_code(y), _stream()), 'bdv_bn_apply')
     return (o, mask) if want_mask else o
 
 
@@ -479,8 +513,8 @@ def bn_backward(dout, relu_mask, y, gamma, save_mean, save_invstd, relu, dgamma=
     ``stat_partial``: the ``(2, rows, C)`` tile sums from ``conv_dgrad(bn_stats=...)``; the statistics pass is skipped."""
     C = y.shape[-1]
     M = y.numel() // C
-    _chk(dout, tuple(y.shape), name='dout')
-    _chk(y, name='y')
+    _chk_act(y, name='y')
+    _chk_act(dout, tuple(y.shape), name='dout', like=y)
     if relu and relu_affine is None:
         _chk(relu_mask, (y.numel() // 32,), dtype=torch.int32, name='relu_mask')
     if relu_affine is not None:
@@ -497,7 +531,7 @@ def bn_backward(dout, relu_mask, y, gamma, save_mean, save_invstd, relu, dgamma=
     _chk(dgamma, (C,), name='dgamma')
     _chk(dbeta, (C,), name='dbeta')
     d = dy if dy is not None else torch.empty_like(y)
-    _chk(d, tuple(y.shape), name='dy')
+    _chk_act(d, tuple(y.shape), name='dy', like=y)
     srows = 0
     if stat_partial is not None:
         _chk(stat_partial, name='stat_partial')
@@ -508,7 +542,7 @@ def bn_backward(dout, relu_mask, y, gamma, save_mean, save_invstd, relu, dgamma=
     check(lib().bdv_bn_backward(_p(dout), _p(relu_mask if relu else None), _p(y), _p(gamma), _p(save_mean), _p(save_invstd),
                                 _p(d), _p(dgamma), _p(dbeta), float(beta_acc), M, C, int(bool(relu)), _p(stat_partial), srows,
                                 _p(relu_affine[0] if relu_affine is not None else None),
-                                _p(relu_affine[1] if relu_affine is not None else None), _p(ws), ws.numel(), _stream()), 'bdv_bn_backward')
+                                _p(relu_affine[1] if relu_affine is not None else None), _p(ws), ws.numel(), _act_code(y), _stream()), 'bdv_bn_backward')
     return d, dgamma, dbeta
 
 
@@ -518,7 +552,7 @@ def bn_backward_maxpool(dpool, pool_idx, relu_mask, y, gamma, save_mean, save_in
     _chk(y, name='y')
     N, H, W, C = y.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    _chk(dpool, (N, Ho, Wo, C), name='dpool')
+    _chk_act(dpool, (N, Ho, Wo, C), name='dpool')      # the pooled tensor's gradient carries the activation storage type; y / dy are fp32
     _chk(pool_idx, (N, Ho, Wo, C), dtype=torch.uint8, name='pool_idx')
     _chk(relu_mask, (y.numel() // 32,), dtype=torch.int32, name='relu_mask')
     for t, n in ((gamma, 'gamma'), (save_mean, 'save_mean'), (save_invstd, 'save_invstd')):
@@ -528,28 +562,28 @@ def bn_backward_maxpool(dpool, pool_idx, relu_mask, y, gamma, save_mean, save_in
     dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
     ws = _bn_ws(N * H * W, C, y.device)
     check(lib().bdv_bn_backward_maxpool(_p(dpool), _p(pool_idx), _p(relu_mask), _p(y), _p(gamma), _p(save_mean), _p(save_invstd),
-                                        _p(dy), _p(dgamma), _p(dbeta), 0.0, N, H, W, C, _p(ws), ws.numel(), _stream()),
+                                        _p(dy), _p(dgamma), _p(dbeta), 0.0, N, H, W, C, _p(ws), ws.numel(), _act_code(dpool), _stream()),
           'bdv_bn_backward_maxpool')
     return dy, dgamma, dbeta
 
 
 def relu_bwd(dout, relu_mask, add=None, g=None):
-    _chk(dout, name='dout')
+    _chk_act(dout, name='dout')
     _chk(relu_mask, (dout.numel() // 32,), dtype=torch.int32, name='relu_mask')
     if add is not None:
-        _chk(add, tuple(dout.shape), name='add')
+        _chk_act(add, tuple(dout.shape), name='add', like=dout)
     r = g if g is not None else torch.empty_like(dout)
-    _chk(r, tuple(dout.shape), name='g')
-    check(lib().bdv_relu_bwd(_p(dout), _p(relu_mask), _p(add), _p(r), dout.numel(), _stream()), 'bdv_relu_bwd')
+    _chk_act(r, tuple(dout.shape), name='g', like=dout)
+    check(lib().bdv_relu_bwd(_p(dout), _p(relu_mask), _p(add), _p(r), dout.numel(), _act_code(dout), _stream()), 'bdv_relu_bwd')
     return r
 
 
 def add(a, b, out=None):
-    _chk(a, name='a')
-    _chk(b, tuple(a.shape), name='b')
+    _chk_act(a, name='a')
+    _chk_act(b, tuple(a.shape), name='b', like=a)
     o = out if out is not None else torch.empty_like(a)
-    _chk(o, tuple(a.shape), name='out')
-    check(lib().bdv_add(_p(a), _p(b), _p(o), a.numel(), _stream()), 'bdv_add')
+    _chk_act(o, tuple(a.shape), name='out', like=a)
+    check(lib().bdv_add(_p(a), _p(b), _p(o), a.numel(), _act_code(a), _stream()), 'bdv_add')
     return o
 
 
@@ -568,27 +602,28 @@ def nchw3_to_nhwc4(x):
     return out
 
 
-def maxpool_fwd(x):
+def maxpool_fwd(x, out_dtype=torch.float32):
+    """``out_dtype``: ``ACT_DTYPE`` at the 2-D stem (the pooled tensor is the first one in the activation storage type)."""
     _chk(x, name='x')
     N, H, W, C = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    out = torch.empty((N, Ho, Wo, C), dtype=out_dtype, device=x.device)
     idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
-    check(lib().bdv_maxpool_fwd(_p(x), _p(out), _p(idx), N, H, W, C, _stream()), 'bdv_maxpool_fwd')
+    check(lib().bdv_maxpool_fwd(_p(x), _p(out), _p(idx), N, H, W, C, _act_code(out), _stream()), 'bdv_maxpool_fwd')
     return out, idx
 
 
-def bn_relu_maxpool_fwd(y, scale, shift):
+def bn_relu_maxpool_fwd(y, scale, shift, out_dtype=torch.float32):
     """Stem tail: relu(y * scale + shift) -> MaxPool2d(3,2,1) in one pass -> (pooled, idx, relu_mask of the activation)."""
     _chk(y, name='y')
     N, H, W, C = y.shape
     _chk(scale, (C,), name='scale')
     _chk(shift, (C,), name='shift')
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=y.device)
+    out = torch.empty((N, Ho, Wo, C), dtype=out_dtype, device=y.device)
     idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=y.device)
     mask = torch.empty(y.numel() // 32, dtype=torch.int32, device=y.device)
-    check(lib().bdv_bn_relu_maxpool_fwd(_p(y), _p(scale), _p(shift), _p(out), _p(idx), _p(mask), N, H, W, C, _stream()),
+    check(lib().bdv_bn_relu_maxpool_fwd(_p(y), _p(scale), _p(shift), _p(out), _p(idx), _p(mask), N, H, W, C, _act_code(out), _stream()),
           'bdv_bn_relu_maxpool_fwd')
     return out, idx, mask
 
@@ -617,26 +652,27 @@ def maxpool_t2_bwd(dout, sel):
 def maxpool_bwd(dout, idx, in_shape):
     N, H, W, C = in_shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    _chk(dout, (N, Ho, Wo, C), name='dout')
+    _chk_act(dout, (N, Ho, Wo, C), name='dout')
     _chk(idx, (N, Ho, Wo, C), dtype=torch.uint8, name='idx')
     dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dout.device)
-    check(lib().bdv_maxpool_bwd(_p(dout), _p(idx), _p(dx), N, H, W, C, _stream()), 'bdv_maxpool_bwd')
+    check(lib().bdv_maxpool_bwd(_p(dout), _p(idx), _p(dx), N, H, W, C, _act_code(dout), _stream()), 'bdv_maxpool_bwd')
     return dx
 
 
 def avgpool_fwd(x):
-    _chk(x, name='x')
+    _chk_act(x, name='x')
     N, H, W, C = x.shape
     out = torch.empty((N, C), dtype=torch.float32, device=x.device)
-    check(lib().bdv_avgpool_fwd(_p(x), _p(out), N, H * W, C, _stream()), 'bdv_avgpool_fwd')
+    check(lib().bdv_avgpool_fwd(_p(x), _p(out), N, H * W, C, _act_code(x), _stream()), 'bdv_avgpool_fwd')
     return out
 
 
-def avgpool_bwd(dout, in_shape):
+def avgpool_bwd(dout, in_shape, dtype=torch.float32):
+    """``dtype``: storage type of the pooled tensor's input (its gradient is written in it)."""
     N, H, W, C = in_shape
     _chk(dout, (N, C), name='dout')
-    dx = torch.empty((N, H, W, C), dtype=torch.float32, device=dout.device)
-    check(lib().bdv_avgpool_bwd(_p(dout), _p(dx), N, H * W, C, _stream()), 'bdv_avgpool_bwd')
+    dx = torch.empty((N, H, W, C), dtype=dtype, device=dout.device)
+    check(lib().bdv_avgpool_bwd(_p(dout), _p(dx), N, H * W, C, _act_code(dx), _stream()), 'bdv_avgpool_bwd')
     return dx
 
 
@@ -690,10 +726,13 @@ def conv_wgrad_partial(dy: torch.Tensor, x: torch.Tensor, g: ConvGeom, x3: Optio
                        dw: Optional[torch.Tensor] = None, pre_bn=None):
     """Split-K partial products of a weight gradient -> (slab (splits, Cout, R, S, Cin), empty dw); reduce them later with
     ``wgrad_reduce_batched`` (the slab must stay alive until then)."""
+    g.act_dtype = _act_code(dy)
     _chk_conv(dy, (g.N, g.Ho, g.Wo, g.Cout), g, 'dy')
     _chk_conv(x, (_in_frames(g), g.H, g.W, g.Cin), g, 'x')
     use_x3 = WGRAD_X3 if x3 is None else x3
     use_pl = use_x3 and USE_PL_WGRAD
+    if g.act_dtype == 1 and not (use_pl and PIECES == 1 and pre_bn is None):
+        raise ValueError("conv_wgrad_partial: bf16 tensors need set_conv_arith('bf16') and the plane kernel")
     if pre_bn is not None:      # x = the producer's raw conv output; its BatchNorm + ReLU is applied in the loader
         if not (use_pl and lib().bdv_conv_wgrad_pre_ok(ctypes.byref(g))):
             raise ValueError('conv_wgrad_partial: pre_bn needs the bf16-piece plane kernel for this geometry')
@@ -903,12 +942,12 @@ def topk_acc(score, labels):
 
 def kd_mse_fwd(cur, prev):
     """cur/prev: any same-shape, same-stride dense tensors (compared in storage order)."""
-    if cur.shape != prev.shape or cur.stride() != prev.stride():
-        raise ValueError('kd_mse: cur and prev need identical shape and strides')
+    if cur.shape != prev.shape or cur.stride() != prev.stride() or cur.dtype != prev.dtype:
+        raise ValueError('kd_mse: cur and prev need identical shape, strides and dtype')
     a, b = _dense_storage(cur), _dense_storage(prev)
     mse = torch.empty(1, dtype=torch.float32, device=cur.device)
     ws = workspace(lib().bdv_reduce_workspace_bytes(), cur.device, 'red')
-    check(lib().bdv_kd_mse_fwd(_p(a), _p(b), _p(mse), a.numel(), _p(ws), ws.numel(), _stream()), 'bdv_kd_mse_fwd')
+    check(lib().bdv_kd_mse_fwd(_p(a), _p(b), _p(mse), a.numel(), _p(ws), ws.numel(), _act_code(a), _stream()), 'bdv_kd_mse_fwd')
     return mse[0]
 
 
@@ -919,15 +958,15 @@ def kd_mse_bwd(cur, prev, gscale_dev, gscale_host=1.0):
         raise ValueError('kd_mse_bwd: could not preserve strides')
     if gscale_dev is not None:
         _chk(gscale_dev.reshape(1), (1,), name='gscale')
-    check(lib().bdv_kd_mse_bwd(_p(a), _p(b), _p(gscale_dev), float(gscale_host), _p(_dense_storage(d)), a.numel(), _stream()),
+    check(lib().bdv_kd_mse_bwd(_p(a), _p(b), _p(gscale_dev), float(gscale_host), _p(_dense_storage(d)), a.numel(), _act_code(a), _stream()),
           'bdv_kd_mse_bwd')
     return d
 
 
 def _dense_storage(t: torch.Tensor) -> torch.Tensor:
     """Flat view over the storage of a dense (possibly permuted) tensor."""
-    if not t.is_cuda or t.dtype != torch.float32:
-        raise RuntimeError('expected an fp32 GPU tensor; there is no CPU fallback')
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError('expected an fp32 (or, in the bf16-storage mode, bf16) GPU tensor; there is no CPU fallback')
     if t.is_contiguous():
         return t.reshape(-1)
     order = sorted(range(t.dim()), key=lambda i: -t.stride(i))

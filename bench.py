@@ -60,14 +60,20 @@ class ConvTimer:
     are separate calls and separate lines."""
 
     def __init__(self):
-        self.records = []      # (tag, flops, start_event, end_event)
+        self.records = []      # (tag, flops, start_event, end_event, bytes)
         self.enabled = False
+        self.only = None       # when set: event pairs only around the launches of this kernel
+        self._tags = {}
 
     def wrap(self, K):
         timer = self
 
         def kernel_tag(kind, g, x3):
-            return K.conv_kernel_name(g, kind, x3).replace(' ', '')
+            key = (kind, g.key(), bool(x3), K.PIECES)
+            tag = timer._tags.get(key)
+            if tag is None:
+                tag = timer._tags[key] = K.conv_kernel_name(g, kind, x3).replace(' ', '')
+            return tag
 
         def make(kind, fn, geom_pos, flag):
             def timed(*a, **kw):
@@ -76,6 +82,9 @@ class ConvTimer:
                 g = a[geom_pos]
                 x3 = kw.get('x3')
                 x3 = getattr(K, flag) if x3 is None else x3
+                tag = kernel_tag(kind, g, x3)
+                if timer.only is not None and tag != timer.only:
+                    return fn(*a, **kw)
                 cin = 3 if g.Cin == 4 else g.Cin
                 flops = 2.0 * g.N * g.Ho * g.Wo * g.Cout * g.R * g.S * max(g.Rt, 1) * cin
                 # algorithmic bytes of the call: every operand and result tensor once (fp32), plus what the fused epilogues stream
@@ -91,13 +100,13 @@ class ConvTimer:
                 e0.record()
                 out = fn(*a, **kw)
                 e1.record()
-                timer.records.append((kernel_tag(kind, g, x3), flops, e0, e1, nbytes))
+                timer.records.append((tag, flops, e0, e1, nbytes))
                 return out
             return timed
 
         def timed_reduce(fn):
             def timed(*a, **kw):
-                if not timer.enabled:
+                if not timer.enabled or timer.only is not None:
                     return fn(*a, **kw)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -121,9 +130,9 @@ class ConvTimer:
         K.conv_wgrad_partial = make('wgrad', K.conv_wgrad_partial, 2, 'WGRAD_X3')
         K.wgrad_reduce_batched = timed_reduce(K.wgrad_reduce_batched)
 
-    def summary(self):
+    def summary(self, records=None):
         by = {}
-        for tag, flops, e0, e1, nbytes in self.records:
+        for tag, flops, e0, e1, nbytes in (self.records if records is None else records):
             ms = e0.elapsed_time(e1)
             d = by.setdefault(tag, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d['launches'] += 1
@@ -254,7 +263,7 @@ def main():
                          "I3D-ResNet50 fwd+bwd+SGD on 32x3x224x224 clips (default batch 16)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--arith', default='bf16x3', choices=['bf16x3', 'f32mfma', 'bf16x1'],
+    ap.add_argument('--arith', default='bf16x3', choices=['bf16x3', 'f32mfma', 'bf16x1', 'bf16'],
                     help="conv arithmetic: 'bf16x3' (default; fp32 products from three bf16 pieces per operand, six bf16 MFMA "
                          "products, fp32 accumulate), 'f32mfma' (v_mfma_f32_32x32x2_f32 kernels), or the REDUCED-PRECISION 'bf16x1' of BASELINE "
                          "config 5 (operands rounded to bf16, one MFMA product, fp32 accumulate and tensors; use with --batch 64; "
@@ -371,17 +380,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        engine.step(batch, loss_fn)
-    sync()
-    t0 = time.perf_counter()
     from bdvcil_amd import functional as Fn
     side_default = Fn._SIDE['enabled']
+    # The per-kernel table (`all_conv_kernels`) comes from ONE untimed step -- the last warm-up step, or an extra step when
+    # --warmup 0 -- with HIP events around every conv call; on that step the weight gradients stay on the main stream (an event
+    # pair must not span work of the other stream).  It names the dominant kernel; the timed region then carries event pairs
+    # around that kernel's launches only (a few dozen per step instead of ~700, which cost 2 % of a step), on every timed
+    # step, with the streams as in production.
+    probe = not args.no_kernel_timing
+    for w in range(args.warmup - (1 if probe else 0)):
+        engine.step(batch, loss_fn)
+    table, dom = {}, None
+    if probe:
+        timer.enabled = True
+        Fn.set_side_stream_enabled(False)
+        engine.step(batch, loss_fn)
+        Fn.set_side_stream_enabled(side_default)
+        timer.enabled = False
+        torch.cuda.synchronize()
+        table = timer.summary()
+        timer.records = []
+        conv_rows = {k: v for k, v in table.items() if v['flops'] > 0}
+        if conv_rows:
+            dom = max(conv_rows, key=lambda k: conv_rows[k]['ms'])
+            timer.only = dom
+    sync()
+    t0 = time.perf_counter()
+    timer.enabled = dom is not None
     for i in range(args.steps):
-        # Per-kernel HIP events on every 8th timed step (the ~700 extra event records of a step cost 2 %).  On those steps
-        # the weight gradients stay on the main stream: a kernel's event pair must not span work of the other stream.
-        timer.enabled = (not args.no_kernel_timing) and i % 8 == 0
-        Fn.set_side_stream_enabled(side_default and not timer.enabled)
         out = engine.step(batch, loss_fn)
     Fn.set_side_stream_enabled(side_default)
     sync()
@@ -399,14 +425,14 @@ def main():
         flop_per_clip = (I3D_FLOP_PER_CLIP if i3d else R50_KD_FLOP_PER_CLIP if cil else R50_FWD_FLOP_PER_CLIP if predict else R50_FLOP_PER_CLIP) if args.depth == 50 else None
         res = {
             'metric': (f'clips/sec fwd+bwd TSM-R50 8x224^2 bs{args.batch}/GPU, bf16 MFMA tiles (BASELINE config 5; not the headline metric)'
-                       if args.arith == 'bf16x1' and args.depth == 50 and not (cil or predict or i3d) else
+                       if args.arith in ('bf16x1', 'bf16') and args.depth == 50 and not (cil or predict or i3d) else
                        'clips/sec fwd+bwd I3D-R50 32x224^2 bs16/GPU (BASELINE config 4; not the headline metric)' if i3d else
                        'clips/sec fwd+bwd TSM-R50 8x224^2 bs32/GPU' if args.depth == 50 else f'clips/sec fwd+bwd TSM-R{args.depth}')
                       + (' (CIL step: bg-mix front-end + KD teacher + LSCLoss)' if cil else '')
                       + (' (predict_step: eval forward + representations, no backward)' if predict else ''),
             'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000.0 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16' if args.arith == 'bf16x1' else 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'bf16' if args.arith in ('bf16x1', 'bf16') else 'f32', 'data': 'synthetic',
             'config': {'workload': ('CIL task-1 step (uint8 bg-mix front-end, frozen teacher forward, 5 feature-KD MSE terms, clip 1.0): ' if cil else '')
                                    + (f'I3D-ResNet50 (ResNet3d, 3x1x1 inflation) fwd+bwd+SGD step, synthetic {args.batch}x3x32x224x224 clips per GPU, ' if i3d else
                                       f'TSM-ResNet{args.depth} ' + ('eval forward + clip representations (predict_step)' if predict else 'fwd+bwd+SGD step') + f', synthetic {args.batch}x8x3x224x224 clips per GPU, ')
@@ -415,23 +441,29 @@ def main():
                                       '(dropped terms <= 2^-24 relative)' if args.arith == 'bf16x3' else
                                       'REDUCED PRECISION (BASELINE config 5): conv operands rounded to bf16, one bf16 MFMA product, fp32 accumulate, '
                                       'fp32 tensors' if args.arith == 'bf16x1' else
+                                      'REDUCED PRECISION (BASELINE config 5): activations and their gradients STORED as bf16 between the stem max-pool and the '
+                                      'average pool, one bf16 MFMA product per step, fp32 accumulate; fp32 BatchNorm statistics, weights, weight gradients, '
+                                      'head and loss' if args.arith == 'bf16' else
                                       'fp32 tensors and results; conv products on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)'),
                        'conv_arith': args.arith,
                        'clips_per_gpu': args.batch, 'global_batch': args.batch * world, 'parallelism': f'dp{world}',
                        'final_loss': round(loss_val, 5)},
         }
+        ms = torch.cuda.memory_stats(dev)
+        res['config']['hbm'] = {'peak_allocated_gb': round(ms.get('allocated_bytes.all.peak', 0) / 2**30, 2),
+                                'peak_reserved_gb': round(ms.get('reserved_bytes.all.peak', 0) / 2**30, 2),
+                                'device_mallocs': ms.get('num_device_alloc', 0), 'device_frees': ms.get('num_device_free', 0),
+                                'alloc_retries': ms.get('num_alloc_retries', 0)}
         if flop_per_clip:
             res['config']['algorithmic_flop_per_clip'] = flop_per_clip
             res['config']['step_tflops'] = round(value / world * flop_per_clip / 1e12, 2)
             res['config']['step_frac_of_f32_mfma_peak'] = round(value / world * flop_per_clip / PEAK_F32_MFMA, 4)
-        if not args.no_kernel_timing and timer.records:
-            by = timer.summary()
-            timed_steps = (args.steps + 7) // 8
-            conv = {k: v for k, v in by.items() if v['flops'] > 0}
-            dom = max(conv, key=lambda k: conv[k]['ms'])
-            d = conv[dom]
+        if dom is not None and timer.records:
+            by = table
+            timed_steps = 1
+            d = timer.summary()[dom]                      # the dominant kernel over the timed region
             bf16_pieces = '_x3_' in dom or '_pl_' in dom
-            peak = PEAK_BF16_MFMA if args.arith == 'bf16x1' and bf16_pieces else PEAK_BF16X3 if bf16_pieces else PEAK_F32_MFMA
+            peak = PEAK_BF16_MFMA if args.arith in ('bf16x1', 'bf16') and bf16_pieces else PEAK_BF16X3 if bf16_pieces else PEAK_F32_MFMA
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
             tot_ms = sum(v['ms'] for v in by.values())
             tot_fl = sum(v['flops'] for v in by.values())
@@ -444,7 +476,7 @@ def main():
                 'traffic_note': f'HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of '
                                 f'this command, profiles/{PROFILE_ROUND}_traffic.json); avg_launch_ms spans the whole C-ABI call '
                                 '(main kernel + its K-split fix-up when the planner uses one)',
-                'kernel': dom, 'launches_per_step': d['launches'] // timed_steps,
+                'kernel': dom, 'launches_per_step': d['launches'] // args.steps,
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                 'rocprof_avg_us': rocprof_avg_us(dom),
                 'algorithmic_gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 2),
@@ -453,7 +485,8 @@ def main():
                                          'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['flops'] else None,
                                          'rocprof_avg_us': rocprof_avg_us(k)} for k, v in sorted(by.items())},
                 'conv_ms_per_step': round(tot_ms / timed_steps, 3), 'conv_tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                'kernel_timed_steps': timed_steps, 'kernel_timing_note': 'HIP events around every conv call on every 8th timed step; on those steps the weight gradients run on the main stream (elsewhere on a side stream, overlapped with the BatchNorm backward passes)',
+                'kernel_timed_steps': args.steps,
+                'kernel_timing_note': 'achieved / avg_launch_ms: HIP events around every launch of the dominant kernel on every timed step, streams as in production; all_conv_kernels / conv_ms_per_step: HIP events around every conv call on ONE untimed step (the last warm-up step) with the weight gradients on the main stream',
             }
         if world == 1 and not args.no_cpu_baseline and not cil and not predict and not i3d:
             res['cpu_baseline'] = cpu_baseline(args.depth, args.classes, args.head, args.loss)

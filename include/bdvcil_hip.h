@@ -31,6 +31,16 @@ extern "C" {
 #define BDV_EINVAL (-1)   /* bad shape / alignment / null pointer */
 #define BDV_EWORKSPACE (-2) /* workspace too small */
 
+/* Activation storage (`act_dtype` arguments, bdv_conv_geom.act_dtype).  BDV_ACT_F32: every activation / gradient tensor is
+ * fp32 (the reference's arithmetic, libs/cil/cil.py:744-756 precision 32; the default and the headline metric).
+ * BDV_ACT_BF16: activations, conv outputs and their gradients are stored as bf16 (BASELINE config 5, the reference's
+ * `precision=16` counterpart; bf16 instead of fp16: same MFMA rate on gfx950, fp32's exponent range, no loss scaler).  Values
+ * widen exactly on load, arithmetic and accumulators stay fp32, stores round to nearest-even; BatchNorm statistics, weights,
+ * weight gradients, ReLU masks and everything after the average pool stay fp32.  Convolutions then run the single-product bf16
+ * MFMA kernels (pieces = 1) only. */
+#define BDV_ACT_F32 0
+#define BDV_ACT_BF16 1
+
 /* Geometry of one 2-D convolution site (UPSTREAM mmaction ResNet ConvModule.conv). */
 typedef struct bdv_conv_geom {
   int32_t N;      /* frames = clips * T */
@@ -53,6 +63,8 @@ typedef struct bdv_conv_geom {
                    * clip; the input holds N * st_t frames and output frame n reads the input frames n * st_t + dt - Rt / 2 of
                    * its clip (zeros outside).  Weights [Cout][Rt][R][S][4]. */
   int32_t st_t;   /* temporal stride (1 or 2) when Rt > 1 */
+  int32_t act_dtype; /* BDV_ACT_F32 | BDV_ACT_BF16: element type of x / y / dy / dx / add_src and of the fused-statistics `y`
+                      * (the plane kernels bdv_conv_fprop_pl / _dgrad_pl / _wgrad_partial_pl with pieces = 1 only; Cin % 32 == 0) */
 } bdv_conv_geom;
 
 const char* bdv_last_error(void);
@@ -80,7 +92,7 @@ int bdv_conv_fprop_stat_rows(const bdv_conv_geom* g);
 typedef struct bdv_conv_affine {
   const float* scale;    /* [Cout] */
   const float* shift;    /* [Cout] */
-  const float* residual; /* [N,Ho,Wo,Cout] or NULL */
+  const void* residual;  /* [N,Ho,Wo,Cout] or NULL (element type: the geometry's act_dtype) */
   int32_t relu;
 } bdv_conv_affine;
 int bdv_conv_fprop(const float* x, const float* w, float* y, const bdv_conv_geom* g, float* bn_partial,
@@ -100,7 +112,7 @@ int bdv_conv_fprop_x3(const float* x, const float* w, float* y, const bdv_conv_g
  * reaches every input pixel (R, S >= 2); the partial then has one block of rows per input-parity class
  * (bdv_conv_dgrad_stat_rows / bdv_conv_dgrad_pl_stat_rows give the total) and is zeroed by the call. */
 typedef struct bdv_bn_stat_fuse {
-  const float* y;            /* [N,H,W,Cin] conv output of the previous unit */
+  const void* y;             /* [N,H,W,Cin] conv output of the previous unit (element type: the geometry's act_dtype) */
   const uint32_t* relu_mask; /* 1 bit per element of dx, or NULL (no ReLU, or the sign is derived: relu_scale) */
   const float* mean;         /* [Cin] saved batch mean */
   const float* invstd;       /* [Cin] */
@@ -161,12 +173,15 @@ int bdv_conv_dgrad_pl_stat_rows(const bdv_conv_geom* g, int pieces);
  * tensor and its ReLU mask are not needed for this consumer (UPSTREAM ConvModule conv -> bn -> relu chains inside Bottleneck /
  * BasicBlock).  Needs pieces = 3, no temporal shift, and bdv_conv_fprop_pre_ok(g); the statistics partial then has
  * bdv_conv_fprop_pre_stat_rows(g) rows. */
-int bdv_conv_fprop_pl(const float* x, const float* w, const void* planes_fprop, float* y, const bdv_conv_geom* g,
+/* g->act_dtype = BDV_ACT_BF16: x, y and affine->residual are bf16 tensors (pieces = 1 only; the accumulators, the fused batch
+ * statistics and the folded BatchNorm arithmetic stay fp32, y is rounded to nearest-even on store); same for dy / dx / add_src /
+ * bn_stat->y of bdv_conv_dgrad_pl and dy / x of bdv_conv_wgrad_partial_pl (weight-gradient slabs stay fp32). */
+int bdv_conv_fprop_pl(const void* x, const float* w, const void* planes_fprop, void* y, const bdv_conv_geom* g,
                       float* bn_partial, const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes, int pieces,
                       const float* pre_scale, const float* pre_shift, void* stream);
 int bdv_conv_fprop_pre_ok(const bdv_conv_geom* g);
 int bdv_conv_fprop_pre_stat_rows(const bdv_conv_geom* g);
-int bdv_conv_dgrad_pl(const float* dy, const float* w, const void* planes_dgrad, float* dx, const float* add_src,
+int bdv_conv_dgrad_pl(const void* dy, const float* w, const void* planes_dgrad, void* dx, const void* add_src,
                       const uint32_t* add_mask_src, const bdv_conv_geom* g, const bdv_bn_stat_fuse* bn_stat, void* workspace,
                       size_t workspace_bytes, int pieces, void* stream);
 
@@ -192,7 +207,7 @@ int bdv_wgrad_reduce_batched(const float* const* slabs, float* const* dws, const
 int bdv_conv_wgrad_pl_splits(const bdv_conv_geom* g);
 /* pre_scale / pre_shift as for bdv_conv_fprop_pl: x is the producer's raw conv output and the activation
  * max(x * pre_scale[ci] + pre_shift[ci], 0) is formed in the loader (needs bdv_conv_wgrad_pre_ok(g)). */
-int bdv_conv_wgrad_partial_pl(const float* dy, const float* x, const bdv_conv_geom* g, void* slab, size_t slab_bytes,
+int bdv_conv_wgrad_partial_pl(const void* dy, const void* x, const bdv_conv_geom* g, void* slab, size_t slab_bytes,
                               int pieces, const float* pre_scale, const float* pre_shift, void* stream);
 int bdv_conv_wgrad_pre_ok(const bdv_conv_geom* g);
 /* EXPERIMENTAL counterpart of bdv_conv_fprop_x3 for the weight gradient's main kernel (128x128 tiles, i.e. Cout and Cin
@@ -223,8 +238,9 @@ int bdv_bn_eval_params(int C, const float* gamma, const float* beta, const float
  * here instead of in a separate pass).  relu_mask (optional, needs C % 32 == 0): bit e of relu_mask[] = (out[e] > 0)
  * for flat element index e -- the 1-bit-per-element ReLU sign mask the backward kernels read instead of the fp32
  * activation. */
-int bdv_bn_apply(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale,
-                 const float* res_shift, float* out, uint32_t* relu_mask, int64_t M, int C, int relu, void* stream);
+/* act_dtype (BDV_ACT_F32 | BDV_ACT_BF16): element type of y, res and out. */
+int bdv_bn_apply(const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
+                 const float* res_shift, void* out, uint32_t* relu_mask, int64_t M, int C, int relu, int act_dtype, void* stream);
 /* backward of (BN-train -> +res -> ReLU): g = dout * (relu_mask bit if relu), dgamma = sum g*xhat,
  * dbeta = sum g, dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).  dgamma/dbeta are written as
  * beta_acc*old + new.  The residual-path gradient is g itself; consumers re-derive it from
@@ -232,14 +248,16 @@ int bdv_bn_apply(const float* y, const float* scale, const float* shift, const f
 /* stat_partial (optional): float[2][stat_rows][C] written by bdv_conv_dgrad(bn_stat); the statistics pass is skipped. */
 /* relu_scale / relu_shift (optional [C] pair, with relu != 0 and relu_mask == NULL): the ReLU sign is derived from y as
  * y * relu_scale + relu_shift > 0, the forward's own expression, for units whose mask was never written. */
-int bdv_bn_backward(const float* dout, const uint32_t* relu_mask, const float* y, const float* gamma,
-                    const float* save_mean, const float* save_invstd, float* dy, float* dgamma,
+/* act_dtype: element type of dout, y and dy (statistics, dgamma / dbeta and the coefficients stay fp32). */
+int bdv_bn_backward(const void* dout, const uint32_t* relu_mask, const void* y, const float* gamma,
+                    const float* save_mean, const float* save_invstd, void* dy, float* dgamma,
                     float* dbeta, float beta_acc, int64_t M, int C, int relu, const float* stat_partial, int stat_rows,
-                    const float* relu_scale, const float* relu_shift, void* workspace, size_t workspace_bytes, void* stream);
+                    const float* relu_scale, const float* relu_shift, void* workspace, size_t workspace_bytes, int act_dtype,
+                    void* stream);
 /* g = dout * relu_mask (+ add) : masked gradient for an identity path that has no conv behind it */
-int bdv_relu_bwd(const float* dout, const uint32_t* relu_mask, const float* add, float* g, int64_t numel, void* stream);
+int bdv_relu_bwd(const void* dout, const uint32_t* relu_mask, const void* add, void* g, int64_t numel, int act_dtype, void* stream);
 /* out = a + b (gradient junctions) */
-int bdv_add(const float* a, const float* b, float* out, int64_t numel, void* stream);
+int bdv_add(const void* a, const void* b, void* out, int64_t numel, int act_dtype, void* stream);
 
 /* ---- stem helpers ------------------------------------------------------------------------ */
 /* (N,3,H,W) fp32 -> (N,H,W,4) fp32, 4th channel 0: boundary layout change for the NCHW batch
@@ -247,8 +265,10 @@ int bdv_add(const float* a, const float* b, float* out, int64_t numel, void* str
 int bdv_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream);
 /* UPSTREAM ResNet.maxpool: MaxPool2d(3, stride 2, pad 1) on NHWC; idx holds the winning tap (0..8)
  * per output element (first maximum in scan order, as torch). */
-int bdv_maxpool_fwd(const float* x, float* out, uint8_t* idx, int N, int H, int W, int C, void* stream);
-int bdv_maxpool_bwd(const float* dout, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream);
+/* out_dtype: element type of `out` (x is the fp32 stem activation): the pooled tensor is the first one stored in the activation
+ * storage type.  bdv_maxpool_bwd: dout_dtype is the type of dout, dx is fp32. */
+int bdv_maxpool_fwd(const float* x, void* out, uint8_t* idx, int N, int H, int W, int C, int out_dtype, void* stream);
+int bdv_maxpool_bwd(const void* dout, const uint8_t* idx, float* dx, int N, int H, int W, int C, int dout_dtype, void* stream);
 /* MaxPool3d((2,1,1), stride (2,1,1)) -- pool2 of UPSTREAM mmaction ResNet3d (I3D, configs/_base_/models/i3d_r50.py:1-27): the
  * element-wise larger of frames 2t and 2t+1 of x [2*frames_out][frame_elems] (frame_elems % 32 == 0; an even number of frames
  * per clip keeps pairs inside a clip).  sel: 1 bit per output element (second frame won); the backward fills dx completely. */
@@ -260,15 +280,18 @@ int bdv_maxpool_t2_bwd(const float* dout, const uint32_t* sel, float* dx, int64_
 /* Backward of the same stem tail: BatchNorm(+ReLU) backward whose incoming gradient is the MaxPool2d(3,2,1) backward of
  * dpool [N,Ho,Wo,C]; that gradient is gathered on the fly in both passes (statistics, apply) and never materialised.
  * dy [N,H,W,C]; dgamma/dbeta as bdv_bn_backward; workspace = bdv_bn_workspace_bytes(N*H*W, C). */
-int bdv_bn_backward_maxpool(const float* dpool, const uint8_t* pool_idx, const uint32_t* relu_mask, const float* y,
+/* The stem conv output y and its gradient dy are fp32 in every storage mode (the stem reads the fp32 NHWC4 frames); the pooled
+ * tensor `out` and its gradient `dpool` carry the activation storage type (out_dtype / dpool_dtype). */
+int bdv_bn_backward_maxpool(const void* dpool, const uint8_t* pool_idx, const uint32_t* relu_mask, const float* y,
                             const float* gamma, const float* save_mean, const float* save_invstd, float* dy, float* dgamma,
                             float* dbeta, float beta_acc, int N, int H, int W, int C, void* workspace,
-                            size_t workspace_bytes, void* stream);
-int bdv_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, uint8_t* idx,
-                            uint32_t* relu_mask, int N, int H, int W, int C, void* stream);
+                            size_t workspace_bytes, int dpool_dtype, void* stream);
+int bdv_bn_relu_maxpool_fwd(const float* y, const float* scale, const float* shift, void* out, uint8_t* idx,
+                            uint32_t* relu_mask, int N, int H, int W, int C, int out_dtype, void* stream);
 /* UPSTREAM TSMHead.avg_pool = AdaptiveAvgPool2d(1): [N,HW,C] -> [N,C] */
-int bdv_avgpool_fwd(const float* x, float* out, int N, int HW, int C, void* stream);
-int bdv_avgpool_bwd(const float* dout, float* dx, int N, int HW, int C, void* stream);
+/* act_dtype: element type of x / dx; the pooled features and their gradient are fp32. */
+int bdv_avgpool_fwd(const void* x, float* out, int N, int HW, int C, int act_dtype, void* stream);
+int bdv_avgpool_bwd(const float* dout, void* dx, int N, int HW, int C, int act_dtype, void* stream);
 
 /* ---- fused background-mix / normalize front-end -------------------------------------------
  * libs/loader/comix_loader.py:72-75,138-145 + UPSTREAM Normalize (img_norm_cfg, config :121-122).
@@ -332,10 +355,12 @@ int bdv_softmax_mean(const float* s, float* out, int B, int n, int K, int apply_
 int bdv_topk_acc(const float* score, const int64_t* labels, float* acc, int B, int K, void* stream);
 /* libs/cil/cil.py:519-541 feature distillation: mse = mean((cur-prev)^2); dcur = gscale*2*(cur-prev)/numel */
 size_t bdv_reduce_workspace_bytes(void);
-int bdv_kd_mse_fwd(const float* cur, const float* prev, float* mse, int64_t numel, void* workspace,
-                   size_t workspace_bytes, void* stream);
-int bdv_kd_mse_bwd(const float* cur, const float* prev, const float* gscale_dev, float gscale_host,
-                   float* dcur, int64_t numel, void* stream);
+/* act_dtype: element type of cur / prev / dcur (the hooked stage outputs carry the activation storage type; the avg_pool
+ * features are fp32 in every mode). */
+int bdv_kd_mse_fwd(const void* cur, const void* prev, float* mse, int64_t numel, void* workspace,
+                   size_t workspace_bytes, int act_dtype, void* stream);
+int bdv_kd_mse_bwd(const void* cur, const void* prev, const float* gscale_dev, float gscale_host,
+                   void* dcur, int64_t numel, int act_dtype, void* stream);
 
 /* ---- representation path: clip representations, NME classifier, class means, herding --------- */
 /* libs/cil/cil.py:501-506 (_extract_repr) + :564-571 (predict_step, extract_repr): feat = the hooked
