@@ -2013,10 +2013,20 @@ __device__ __forceinline__ void pl_pipeline2(int n, LoadF&& load, StoreF&& store
   }
 }
 
+// Occupancy of the 8-wave plane kernels (second __launch_bounds__ argument = waves per SIMD).  NP = 3: one workgroup per CU (two
+// waves per SIMD, 256 VGPRs): the K loop is MFMA-bound and the three-plane stages fill the LDS.  NP = 1 (single-product
+// arithmetic, BASELINE config 5): a sixth of the MFMA work per K-step leaves the loop waiting for its global loads (1.2 us per
+// K-step measured, 0.27 us of it MFMA time), and a one-plane stage is a third of the LDS -- two workgroups per CU (four waves
+// per SIMD, 128 VGPRs) keep twice the loads in flight and let one workgroup's MFMA phase run under the other's wait.  Only where
+// the tile fits 128 VGPRs: measured per training step at batch 64 (gpurun_out/np1_*.log), fprop 128x256 7.40 -> 6.39 ms (52 - 64
+// bytes of scratch), fprop 256x64 1.97 -> 1.39, dgrad 256x64 3.64 -> 3.19; the others spill their accumulators (236 - 600 bytes
+// per lane) and run 2 - 3 x slower (dgrad 128x256 13.3 -> 25.3 ms), so they keep one workgroup per CU.
+constexpr int pl_waves_per_simd(int waves, int np, bool fits128) { return np == 1 && waves == 8 && fits128 ? 4 : waves / 4; }
+
 // ---- fprop ------------------------------------------------------------------------------------
 // ES: bytes per element of x / y / the residual (4 = fp32, 2 = bf16 storage: NP = 1 only, the loader's conversion is then exact)
 template <int BM, int BN, int WM, int WN, int NBUF, int NP = 3, bool PRE = false, int ES = 4>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_kernel(const void* __restrict__ x,
+__global__ __launch_bounds__(64 * WM * WN, pl_waves_per_simd(WM * WN, NP, BN == 64 || (BM == 128 && BN == 256))) void conv_fprop_pl_kernel(const void* __restrict__ x,
                                                                                       const unsigned short* __restrict__ wp,
                                                                                       void* __restrict__ y, Geom g, int NT, Work wk,
                                                                                       float* __restrict__ slab, FpropEpi epi) {
@@ -2024,9 +2034,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM * 8 / NTHR;    // float4 loads of the activation tile per thread and K-step
   constexpr int BPP = (BN * 4 + NTHR - 1) / NTHR;   // 16-byte loads per weight plane per thread and K-step
-  constexpr int PA = BM * 64, PB = BN * 64, STAGE = 3 * (PA + PB);
-  static_assert(AP >= 1 && NBUF * STAGE >= WM * 32 * BN * 4, "tile / epilogue staging do not fit");
-  __shared__ __attribute__((aligned(16))) unsigned char smem_b[NBUF * STAGE];
+  constexpr int PA = BM * 64, PB = BN * 64, STAGE = NP * (PA + PB);   // NP planes per operand and stage
+  constexpr int SMEM = NBUF * STAGE >= WM * 32 * BN * 4 ? NBUF * STAGE : WM * 32 * BN * 4;   // K-loop stages, then the epilogue's staging
+  static_assert(AP >= 1 && SMEM <= 160 * 1024, "tile / epilogue staging do not fit");
+  __shared__ __attribute__((aligned(16))) unsigned char smem_b[SMEM];
   float* const smem = reinterpret_cast<float*>(smem_b);
 
   const int nk = g.Ktot / BK;
@@ -2118,7 +2129,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
   auto store = [&](int stage, auto set) __attribute__((always_inline)) {
     constexpr int SET = decltype(set)::value;
     unsigned char* const As = smem_b + stage * STAGE;
-    unsigned char* const Bs = As + 3 * PA;
+    unsigned char* const Bs = As + NP * PA;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       float4 v = ra[SET][p];
@@ -2143,7 +2154,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
 
   if constexpr (NBUF == 2) {
     pl_pipeline2(it.ke - it.kb, load, store, [&](int stage) __attribute__((always_inline)) {
-      mma_stage_pl<BM, BN, WM, WN, NP>(smem_b + stage * STAGE, smem_b + stage * STAGE + 3 * PA, acc, fa, fb);
+      mma_stage_pl<BM, BN, WM, WN, NP>(smem_b + stage * STAGE, smem_b + stage * STAGE + NP * PA, acc, fa, fb);
     });
   } else {
     load(PlSet0{});
@@ -2152,7 +2163,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
       store(0, PlSet0{});
       __syncthreads();
       if (kt + 1 < it.ke) load(PlSet0{});
-      mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + 3 * PA, acc, fa, fb);
+      mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + NP * PA, acc, fa, fb);
     }
   }
 
@@ -2166,7 +2177,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_fprop_pl_ker
 // ---- dgrad ------------------------------------------------------------------------------------
 // dp = the D planes of bdv_conv_split_weights: B rows = input channels ci, contraction over (tap, co) with co contiguous.
 template <int BM, int BN, int WM, int WN, int NBUF, int NP = 3, int ES = 4>
-__global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : (WM * WN) / 4) void conv_dgrad_pl_kernel(const void* __restrict__ dy,
+__global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM * WN, NP, BN == 64)) void conv_dgrad_pl_kernel(const void* __restrict__ dy,
                                                                                       const unsigned short* __restrict__ dp,
                                                                                       void* __restrict__ dx,
                                                                                       const void* __restrict__ add_src,
@@ -2177,9 +2188,10 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : (WM * WN) / 4) void co
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int AP = BM * 8 / NTHR;
   constexpr int BPP = (BN * 4 + NTHR - 1) / NTHR;
-  constexpr int PA = BM * 64, PB = BN * 64, STAGE = 3 * (PA + PB);
-  static_assert(AP >= 1 && NBUF * STAGE >= WM * 32 * BN * 4, "tile / epilogue staging do not fit");
-  __shared__ __attribute__((aligned(16))) unsigned char smem_b[NBUF * STAGE];
+  constexpr int PA = BM * 64, PB = BN * 64, STAGE = NP * (PA + PB);   // NP planes per operand and stage
+  constexpr int SMEM = NBUF * STAGE >= WM * 32 * BN * 4 ? NBUF * STAGE : WM * 32 * BN * 4;   // K-loop stages, then the epilogue's staging
+  static_assert(AP >= 1 && SMEM <= 160 * 1024, "tile / epilogue staging do not fit");
+  __shared__ __attribute__((aligned(16))) unsigned char smem_b[SMEM];
   float* const smem = reinterpret_cast<float*>(smem_b);
 
   // parity class of the input pixel (stride 1: a single class)
@@ -2283,7 +2295,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : (WM * WN) / 4) void co
   auto store = [&](int stage, auto set) __attribute__((always_inline)) {
     constexpr int SET = decltype(set)::value;
     unsigned char* const As = smem_b + stage * STAGE;
-    unsigned char* const Bs = As + 3 * PA;
+    unsigned char* const Bs = As + NP * PA;
 #pragma unroll
     for (int p = 0; p < AP; ++p) pl_split_store_at<NP>(As + st_a + (NTHR / 8) * p * 64, PA, ra[SET][p]);
     if (b_active) {
@@ -2300,7 +2312,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : (WM * WN) / 4) void co
   if (it.ke > it.kb) {
     if constexpr (NBUF == 2) {
       pl_pipeline2(it.ke - it.kb, load, store, [&](int stage) __attribute__((always_inline)) {
-        mma_stage_pl<BM, BN, WM, WN, NP>(smem_b + stage * STAGE, smem_b + stage * STAGE + 3 * PA, acc, fa, fb);
+        mma_stage_pl<BM, BN, WM, WN, NP>(smem_b + stage * STAGE, smem_b + stage * STAGE + NP * PA, acc, fa, fb);
       });
     } else {
       load(PlSet0{});
@@ -2309,7 +2321,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : (WM * WN) / 4) void co
         store(0, PlSet0{});
         __syncthreads();
         if (kt + 1 < it.ke) load(PlSet0{});
-        mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + 3 * PA, acc, fa, fb);
+        mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + NP * PA, acc, fa, fb);
       }
     }
   }
@@ -2829,11 +2841,20 @@ int pl_tile_override() {
 // override the rules wherever the forced tile divides the column count.
 int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride, int pieces = 3, bool shifted = false) {
   const int forced = pl_tile_override();
-  if (pieces == 1)  // the single-product arithmetic only exists in the 8-wave kernels
-    return forced >= 0 && forced < kNumPlCfg && ncols % kPlCfg[forced].BN == 0 && (forced != 4 || (dgrad && stride == 1)) ? forced
-           : ncols % 256 == 0 ? 0 : ncols % 128 == 0 ? 1 : ncols % 64 == 0 ? 3 : -1;
+  if (pieces == 1) {  // the single-product arithmetic only exists in the plane kernels
+    // A sixth of the MFMA work per K-step: the loop waits for its loads, not for the matrix pipe.  For the data gradient (whose
+    // epilogue streams the residual, the mask and the statistics operands on top) many small workgroups hide that better than one
+    // large one: 64x128 tiles, four workgroups per CU, for stride 1 and multiples of 128 columns.  Training step at batch 64,
+    // bf16 storage: dgrad 18.9 -> 15.6 ms, 1100 -> 1158 clips/s; fp32 tensors: level (gpurun_out/np1_*.log).  The same tile for
+    // fprop (8.8 against 8.0 ms) and 128x128 weight-gradient tiles (7.4 against 7.7 ms) were measured and left out.
+    const bool small_ok = dgrad && stride == 1;
+    if (forced >= 0 && forced < kNumPlCfg && ncols % kPlCfg[forced].BN == 0 && (forced != 4 || small_ok)) return forced;
+    static const bool np1_small = getenv("BDVCIL_NP1_SMALL_TILES") == nullptr || atoi(getenv("BDVCIL_NP1_SMALL_TILES")) != 0;
+    if (np1_small && small_ok && ncols % 128 == 0) return 4;
+    return ncols % 256 == 0 ? 0 : ncols % 128 == 0 ? 1 : ncols % 64 == 0 ? 3 : -1;
+  }
   if (forced == kNumPlCfg) return -1;  // "none": the kernels of the other family everywhere
-  if (forced >= 0 && ncols % kPlCfg[forced].BN == 0 && (forced != 4 || (dgrad && stride == 1))) return forced;
+  if (forced >= 0 && ncols % kPlCfg[forced].BN == 0 && (forced != 4 || (dgrad && stride == 1))) return forced;   // (three pieces: the 64x128 tile exists for dgrad only)
   if (ncols % 64 != 0) return -1;
   if (ncols % 128 != 0) return taps > 1 ? 3 : -1;
   if (!dgrad) {
@@ -2986,8 +3007,6 @@ WgradPlPlan plan_wgrad_pl(const bdv_conv_geom* g) {
   static const int kBM[6] = {0, 64, 64, 256, 64, 64}, kBN[6] = {0, 192, 64, 64, 256, 256};
   p.BM = p.form == 0 ? (g->Cout % 256 == 0 ? 256 : 128) : kBM[p.form];
   p.BN = p.form == 0 ? (g->Cin % 256 == 0 ? 256 : 128) : kBN[p.form];
-  // (256 x 256 one-stage against the two-stage 128 x 256 / 256 x 128 tiles on the sites that allow both: 0.295-0.315 against
-  // 0.308-0.329 ms on the 3x3 sites, 0.153-0.163 against 0.150-0.158 on the 1x1 sites: the larger tile stays)
   p.MTw = g->Cout / p.BM;
   p.NTw = ((g->Rt > 1 ? g->Rt : 1) * g->R * g->S * g->Cin + p.BN - 1) / p.BN;
   const int64_t M = (int64_t)g->N * g->Ho * g->Wo;

@@ -80,6 +80,7 @@ class ConvTimer:
                 if not timer.enabled:
                     return fn(*a, **kw)
                 g = a[geom_pos]
+                g.act_dtype = 1 if a[0].dtype == torch.bfloat16 else 0      # (the call sets it too: the kernel name depends on it)
                 x3 = kw.get('x3')
                 x3 = getattr(K, flag) if x3 is None else x3
                 tag = kernel_tag(kind, g, x3)
@@ -385,8 +386,7 @@ def main():
     # The per-kernel table (`all_conv_kernels`) comes from ONE untimed step -- the last warm-up step, or an extra step when
     # --warmup 0 -- with HIP events around every conv call; on that step the weight gradients stay on the main stream (an event
     # pair must not span work of the other stream).  It names the dominant kernel; the timed region then carries event pairs
-    # around that kernel's launches only (a few dozen per step instead of ~700, which cost 2 % of a step), on every timed
-    # step, with the streams as in production.
+    # around that kernel's launches only (a few dozen instead of ~700 per sampled step), on one timed step in 16.
     probe = not args.no_kernel_timing
     for w in range(args.warmup - (1 if probe else 0)):
         engine.step(batch, loss_fn)
@@ -406,8 +406,14 @@ def main():
             timer.only = dom
     sync()
     t0 = time.perf_counter()
-    timer.enabled = dom is not None
+    sampled = 0
     for i in range(args.steps):
+        # one timed step in 16 (the 9th, 25th, ...; the middle one of a short run) carries the event pairs, with the side streams
+        # off for that step: a pair then brackets the kernel alone, not the kernel stretched by what shares the GPU with it
+        sample = dom is not None and (i % 16 == 8 or (args.steps <= 8 and i == args.steps // 2))
+        timer.enabled = sample
+        Fn.set_side_stream_enabled(side_default and not sample)
+        sampled += int(sample)
         out = engine.step(batch, loss_fn)
     Fn.set_side_stream_enabled(side_default)
     sync()
@@ -476,7 +482,7 @@ def main():
                 'traffic_note': f'HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of '
                                 f'this command, profiles/{PROFILE_ROUND}_traffic.json); avg_launch_ms spans the whole C-ABI call '
                                 '(main kernel + its K-split fix-up when the planner uses one)',
-                'kernel': dom, 'launches_per_step': d['launches'] // args.steps,
+                'kernel': dom, 'launches_per_step': d['launches'] // max(sampled, 1),
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                 'rocprof_avg_us': rocprof_avg_us(dom),
                 'algorithmic_gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 2),
@@ -485,8 +491,8 @@ def main():
                                          'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['flops'] else None,
                                          'rocprof_avg_us': rocprof_avg_us(k)} for k, v in sorted(by.items())},
                 'conv_ms_per_step': round(tot_ms / timed_steps, 3), 'conv_tflops': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                'kernel_timed_steps': args.steps,
-                'kernel_timing_note': 'achieved / avg_launch_ms: HIP events around every launch of the dominant kernel on every timed step, streams as in production; all_conv_kernels / conv_ms_per_step: HIP events around every conv call on ONE untimed step (the last warm-up step) with the weight gradients on the main stream',
+                'kernel_timed_steps': sampled,
+                'kernel_timing_note': 'achieved / avg_launch_ms: HIP events around every launch of the dominant kernel on one timed step in 16, with the side streams off on that step (a pair brackets the kernel alone); all_conv_kernels / conv_ms_per_step: HIP events around every conv call on ONE untimed step (the last warm-up step), side streams off',
             }
         if world == 1 and not args.no_cpu_baseline and not cil and not predict and not i3d:
             res['cpu_baseline'] = cpu_baseline(args.depth, args.classes, args.head, args.loss)

@@ -20,6 +20,9 @@ timeout -k 10 300 python bench.py --workload cil --steps 8 --warmup 2 --no-cpu-b
 timeout -k 10 300 python bench.py --workload predict --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/$R/bench_predict.json 2> gpurun_out/$R/bench_predict.err
 timeout -k 10 300 python bench.py --workload i3d --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/$R/bench_i3d.json 2> gpurun_out/$R/bench_i3d.err
 timeout -k 10 300 python bench.py --arith bf16x1 --batch 64 --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/$R/bench_bf16x1.json 2> gpurun_out/$R/bench_bf16x1.err
+timeout -k 10 300 python bench.py --arith bf16 --batch 64 --no-cpu-baseline > gpurun_out/$R/bench_bf16.json 2> gpurun_out/$R/bench_bf16.err
+timeout -k 10 300 python bench.py --arith bf16 --workload cil --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/$R/bench_cil_bf16.json 2> gpurun_out/$R/bench_cil_bf16.err
+timeout -k 10 300 python bench.py --arith bf16 --workload predict --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/$R/bench_predict_bf16.json 2> gpurun_out/$R/bench_predict_bf16.err
 timeout -k 10 300 python bench.py --depth 34 --no-cpu-baseline > gpurun_out/$R/bench_r34.json 2> gpurun_out/$R/bench_r34.err
 timeout -k 10 300 python bench.py --arith f32mfma --no-cpu-baseline > gpurun_out/$R/bench_f32mfma.json 2> gpurun_out/$R/bench_f32mfma.err
 find gpurun_out/$R -name "*counter_collection.csv" -size +8M -delete
