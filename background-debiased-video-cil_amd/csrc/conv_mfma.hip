@@ -2032,7 +2032,10 @@ __global__ __launch_bounds__(64 * WM * WN, pl_waves_per_simd(WM * WN, NP, BN == 
                                                                                       float* __restrict__ slab, FpropEpi epi) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int AP = BM * 8 / NTHR;    // float4 loads of the activation tile per thread and K-step
+  // a thread's unit of the activation tile is 16 bytes: 4 fp32 values (8 threads per 32-deep row) or 8 bf16 values (4 threads per
+  // row; the bytes go to LDS as they are: the image of a bf16 row IS the tensor's row)
+  constexpr int KG = ES == 2 ? 4 : 8;
+  constexpr int AP = BM * KG / NTHR;    // 16-byte loads of the activation tile per thread and K-step
   constexpr int BPP = (BN * 4 + NTHR - 1) / NTHR;   // 16-byte loads per weight plane per thread and K-step
   constexpr int PA = BM * 64, PB = BN * 64, STAGE = NP * (PA + PB);   // NP planes per operand and stage
   constexpr int SMEM = NBUF * STAGE >= WM * 32 * BN * 4 ? NBUF * STAGE : WM * 32 * BN * 4;   // K-loop stages, then the epilogue's staging
@@ -2047,7 +2050,7 @@ __global__ __launch_bounds__(64 * WM * WN, pl_waves_per_simd(WM * WN, NP, BN == 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int arow = tid >> 3, kg = tid & 7;
+  const int arow = tid / KG, kg = tid % KG;
   const int brow = tid >> 2, bc = tid & 3;
   const int HoWo = g.Ho * g.Wo;
   static_assert(ES == 4 || (NP == 1 && !PRE), "bf16 storage: single-product arithmetic only");
@@ -2060,7 +2063,7 @@ __global__ __launch_bounds__(64 * WM * WN, pl_waves_per_simd(WM * WN, NP, BN == 
   int a_base[AP], a_t[AP], a_hi0[AP], a_wi0[AP];
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
-    const int m = mt * BM + arow + (NTHR / 8) * p;
+    const int m = mt * BM + arow + (NTHR / KG) * p;
     const bool ok = m < g.M;
     int n, rem, ho, wo;
     fast_divmod(ok ? m : 0, HoWo, g.rcp_HoWo, n, rem);
@@ -2068,7 +2071,7 @@ __global__ __launch_bounds__(64 * WM * WN, pl_waves_per_simd(WM * WN, NP, BN == 
     a_t[p] = n % g.T;
     a_hi0[p] = ok ? ho * g.stride - g.pad : -(1 << 20);  // rows past M fail every bounds test
     a_wi0[p] = wo * g.stride - g.pad_w;
-    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad_w) * g.Cin * ES + 4 * ES * kg;
+    a_base[p] = ((n * g.H + ho * g.stride - g.pad) * g.W + wo * g.stride - g.pad_w) * g.Cin * ES + 16 * kg;
   }
   int b_base[BPP];
   const bool b_active = BN * 4 >= NTHR || tid < BN * 4;   // a 64-row weight tile is loaded by the first four waves only
@@ -2095,18 +2098,18 @@ __global__ __launch_bounds__(64 * WM * WN, pl_waves_per_simd(WM * WN, NP, BN == 
   auto load = [&](auto set) __attribute__((always_inline)) {
     constexpr int SET = decltype(set)::value;
     if constexpr (PRE) {
-      psc[SET] = *reinterpret_cast<const float4*>(epi.pre_scale + chunk * BK + 4 * kg);
+      psc[SET] = *reinterpret_cast<const float4*>(epi.pre_scale + chunk * BK + 4 * kg);   // (PRE: fp32 tensors only, KG = 8)
       psh[SET] = *reinterpret_cast<const float4*>(epi.pre_shift + chunk * BK + 4 * kg);
       pvalid[SET] = 0u;
     }
-    const int cls = shift_class(chunk * BK + 4 * kg, g.fold);
+    const int cls = shift_class(chunk * BK + (BK / KG) * kg, g.fold);
     const int koff_a = ((r * g.W + s) * g.Cin + chunk * BK) * ES;
     const int koff_b = kt_w * g.Cout * 64;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       const bool v = (unsigned)(a_hi0[p] + r) < (unsigned)g.H && (unsigned)(a_wi0[p] + s) < (unsigned)g.W &&
                      (unsigned)(a_t[p] + cls) < (unsigned)g.T;
-      ra[SET][p] = buf_ld4<ES>(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB));
+      ra[SET][p] = buf_load16(xr, (a_base[p] + koff_a + cls * frame_bytes) | (v ? 0 : kOOB), 0);   // ES = 2: eight bf16, as raw bits
       if constexpr (PRE) pvalid[SET] |= (v ? 1u : 0u) << p;
     }
 #pragma unroll
@@ -2123,7 +2126,7 @@ __global__ __launch_bounds__(64 * WM * WN, pl_waves_per_simd(WM * WN, NP, BN == 
     chunk += wr_;
   };
   // LDS offsets of this thread: stores (rows arow + 64 p / brow + 128 q keep (row >> 2) & 3) and fragment reads
-  const int st_a = pl_off(arow, kg >> 1) + 8 * (kg & 1), st_b = pl_off(brow, bc);
+  const int st_a = ES == 2 ? pl_off(arow, kg) : pl_off(arow, kg >> 1) + 8 * (kg & 1), st_b = pl_off(brow, bc);
   const int fa[2] = {pl_frag_off(32 * wm, 0, lane), pl_frag_off(32 * wm, 1, lane)};
   const int fb[2] = {pl_frag_off(32 * wn, 0, lane), pl_frag_off(32 * wn, 1, lane)};
   auto store = [&](int stage, auto set) __attribute__((always_inline)) {
@@ -2140,7 +2143,8 @@ __global__ __launch_bounds__(64 * WM * WN, pl_waves_per_simd(WM * WN, NP, BN == 
         v.z = ok ? fmaxf(fmaf(v.z, psc[SET].z, psh[SET].z), 0.f) : 0.f;
         v.w = ok ? fmaxf(fmaf(v.w, psc[SET].w, psh[SET].w), 0.f) : 0.f;
       }
-      pl_split_store_at<NP>(As + st_a + (NTHR / 8) * p * 64, PA, v);
+      if constexpr (ES == 2) *reinterpret_cast<float4*>(As + st_a + (NTHR / KG) * p * 64) = v;
+      else pl_split_store_at<NP>(As + st_a + (NTHR / KG) * p * 64, PA, v);
     }
     if (b_active) {
 #pragma unroll
@@ -2186,7 +2190,8 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM *
                                                                                       BnStat stat) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int AP = BM * 8 / NTHR;
+  constexpr int KG = ES == 2 ? 4 : 8;   // threads per 32-deep row of the activation tile: 16 bytes each (conv_fprop_pl_kernel)
+  constexpr int AP = BM * KG / NTHR;
   constexpr int BPP = (BN * 4 + NTHR - 1) / NTHR;
   constexpr int PA = BM * 64, PB = BN * 64, STAGE = NP * (PA + PB);   // NP planes per operand and stage
   constexpr int SMEM = NBUF * STAGE >= WM * 32 * BN * 4 ? NBUF * STAGE : WM * 32 * BN * 4;   // K-loop stages, then the epilogue's staging
@@ -2228,7 +2233,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM *
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int arow = tid >> 3, kg = tid & 7;
+  const int arow = tid / KG, kg = tid % KG;
   const int brow = tid >> 2, bc = tid & 3;
   const int HcWc = Hc * Wc;
   const int RS = g.R * g.S;
@@ -2239,7 +2244,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM *
   int a_base[AP], a_h[AP], a_w[AP];
 #pragma unroll
   for (int p = 0; p < AP; ++p) {
-    const int m = mt * BM + arow + (NTHR / 8) * p;
+    const int m = mt * BM + arow + (NTHR / KG) * p;
     const bool ok = m < Mc;
     const int mm = ok ? m : 0;
     const int n = mm / HcWc;
@@ -2247,7 +2252,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM *
     const int hc = rem / Wc, wc = rem - hc * Wc;
     a_h[p] = ok ? hc + bh : -(1 << 20);
     a_w[p] = wc + bw;
-    a_base[p] = ((n * g.Ho + hc + bh) * g.Wo + wc + bw) * g.Cout * ES + 4 * ES * kg;
+    a_base[p] = ((n * g.Ho + hc + bh) * g.Wo + wc + bw) * g.Cout * ES + 16 * kg;
   }
   int b_base[BPP];
   const bool b_active = BN * 4 >= NTHR || tid < BN * 4;   // a 64-row weight tile is loaded by the first four waves only
@@ -2274,7 +2279,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM *
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       const bool v = (unsigned)(a_h[p] - ir) < (unsigned)g.Ho && (unsigned)(a_w[p] - is) < (unsigned)g.Wo;
-      ra[SET][p] = buf_ld4<ES>(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB));
+      ra[SET][p] = buf_load16(yr, (a_base[p] + koff_a) | (v ? 0 : kOOB), 0);   // ES = 2: eight bf16, as raw bits
     }
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl)
@@ -2289,7 +2294,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM *
     chunk += w2;
   };
   // LDS offsets of this thread: stores (rows arow + 64 p / brow + 128 q keep (row >> 2) & 3) and fragment reads
-  const int st_a = pl_off(arow, kg >> 1) + 8 * (kg & 1), st_b = pl_off(brow, bc);
+  const int st_a = ES == 2 ? pl_off(arow, kg) : pl_off(arow, kg >> 1) + 8 * (kg & 1), st_b = pl_off(brow, bc);
   const int fa[2] = {pl_frag_off(32 * wm, 0, lane), pl_frag_off(32 * wm, 1, lane)};
   const int fb[2] = {pl_frag_off(32 * wn, 0, lane), pl_frag_off(32 * wn, 1, lane)};
   auto store = [&](int stage, auto set) __attribute__((always_inline)) {
@@ -2297,7 +2302,10 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM *
     unsigned char* const As = smem_b + stage * STAGE;
     unsigned char* const Bs = As + NP * PA;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) pl_split_store_at<NP>(As + st_a + (NTHR / 8) * p * 64, PA, ra[SET][p]);
+    for (int p = 0; p < AP; ++p) {
+      if constexpr (ES == 2) *reinterpret_cast<float4*>(As + st_a + (NTHR / KG) * p * 64) = ra[SET][p];
+      else pl_split_store_at<NP>(As + st_a + (NTHR / KG) * p * 64, PA, ra[SET][p]);
+    }
     if (b_active) {
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl)
@@ -2391,8 +2399,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const vo
                                                                          const float* __restrict__ pre_shift) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static_assert(TM >= 1 && TN >= 1 && (32 * (BM / 4)) % NTHR == 0 && (32 * (BN / 4)) % NTHR == 0, "tile / thread mapping");
-  constexpr int AV = BM / 4, BV = BN / 4;
+  // a thread's unit of either operand is 16 bytes of one pixel's channels: 4 fp32 or 8 bf16 values (bf16: stored to LDS as they are)
+  constexpr int GV = ES == 2 ? 8 : 4;
+  static_assert(TM >= 1 && TN >= 1 && (32 * (BM / GV)) % NTHR == 0 && (32 * (BN / GV)) % NTHR == 0, "tile / thread mapping");
+  static_assert(ES == 4 || NP == 1, "bf16 storage: single-product arithmetic (and Cin % 8 == 0: a 16-byte unit stays inside a filter tap)");
+  constexpr int AV = BM / GV, BV = BN / GV;
   static_assert(KW == 32 || KW == 16, "pixels per stage");
   constexpr int NST = 32 / KW;          // LDS stages = register sets
   constexpr int AP = KW * AV / NTHR, BP = KW * BV / NTHR;
@@ -2427,7 +2438,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const vo
   for (int p = 0; p < AP; ++p) {
     const int idx = tid + NTHR * p;
     a_krow[p] = idx / AV;
-    a_off[p] = (a_krow[p] * g.Cout + mt * BM + 4 * (idx % AV)) * ES;
+    a_off[p] = (a_krow[p] * g.Cout + mt * BM + GV * (idx % AV)) * ES;
   }
   // B: GEMM column nt * BN + j = (tap, ci) with ci fastest; rows = input pixels of the tap
   int b_krow[BP], b_off[BP], b_cls[BP], b_r[BP], b_s[BP];
@@ -2435,7 +2446,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const vo
   for (int p = 0; p < BP; ++p) {
     const int idx = tid + NTHR * p;
     b_krow[p] = idx / BV;
-    const int col = nt * BN + 4 * (idx % BV);
+    const int col = nt * BN + GV * (idx % BV);
     const int tap = MTAP ? col / g.Cin : (nt * BN) / g.Cin;   // one tap per tile unless MTAP; tap = (dt * R + r) * S + s
     const int ci = col - tap * g.Cin;
     const int dt = MTAP ? tap / (g.R * g.S) : 0, rs = tap - dt * g.R * g.S;
@@ -2494,7 +2505,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const vo
     bvalid[SET] = 0u;
 #pragma unroll
     for (int p = 0; p < AP; ++p)  // rows past M lie past num_records: zeros
-      ra[SET][p] = buf_ld4<ES>(yr, a_off[p] + m0 * g.Cout * ES);
+      ra[SET][p] = buf_load16(yr, a_off[p] + m0 * g.Cout * ES, 0);
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
       const int m = m0 + b_krow[p];
@@ -2526,7 +2537,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const vo
       }
       const bool v = mok && (unsigned)(hi + b_r[p]) < (unsigned)g.H && (unsigned)(wi_ + b_s[p]) < (unsigned)g.W &&
                      (unsigned)(t * g.st_t + b_cls[p]) < (unsigned)(g.T * g.st_t);
-      rb[SET][p] = buf_ld4<ES>(xr, off | (v ? 0 : kOOB));
+      rb[SET][p] = buf_load16(xr, off | (v ? 0 : kOOB), 0);
       bvalid[SET] |= (v ? 1u : 0u) << p;
     }
   };
@@ -2539,7 +2550,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const vo
     unsigned char* const As = smem_b + stage * STAGE;
     unsigned char* const Bs = As + 3 * PLANE_A;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) pl_store_rows<BM, NP, KW>(As, a_krow[p], (tid + NTHR * p) % AV, ra[SET][p]);
+    for (int p = 0; p < AP; ++p) {
+      if constexpr (ES == 2) *reinterpret_cast<float4*>(As + a_krow[p] * PITCH_A + 16 * ((tid + NTHR * p) % AV)) = ra[SET][p];
+      else pl_store_rows<BM, NP, KW>(As, a_krow[p], (tid + NTHR * p) % AV, ra[SET][p]);
+    }
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
       const int c4 = (tid + NTHR * p) % BV;
@@ -2552,7 +2566,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const vo
         v.z = ok ? fmaxf(fmaf(v.z, sc.z, sh.z), 0.f) : 0.f;
         v.w = ok ? fmaxf(fmaf(v.w, sc.w, sh.w), 0.f) : 0.f;
       }
-      pl_store_rows<BN, NP, KW>(Bs, b_krow[p], c4, v);
+      if constexpr (ES == 2) *reinterpret_cast<float4*>(Bs + b_krow[p] * PITCH_B + 16 * c4) = v;
+      else pl_store_rows<BN, NP, KW>(Bs, b_krow[p], c4, v);
     }
   };
   auto mma = [&](int stage) __attribute__((always_inline)) {
@@ -3643,14 +3658,14 @@ extern "C" int bdv_conv_wgrad_partial_pl(const void* dy, const void* x, const bd
                      (float*)slab, g, p.MTw, p.NTw, p.kt_per_split, pre_scale, pre_shift)
 #define BDV_WGRAD_PL(BM_, BN_, WM_, WN_, MTAP_, KW_)                                                                             \
   do {                                                                                                                           \
-    if (h16 && incr) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 1, MTAP_, KW_, 2);                                                  \
-    else if (h16) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 1, MTAP_, KW_, 2);                                                    \
+    if (h16 && incr) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 1, MTAP_, (KW_ == 16 ? 32 : KW_), 2);                               \
+    else if (h16) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 1, MTAP_, (KW_ == 16 ? 32 : KW_), 2);                                 \
     else if (incr && pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 3, MTAP_, KW_, 4);                                     \
     else if (pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 3, MTAP_, KW_, 4);                                            \
     else if (incr) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 1, MTAP_, KW_, 4);                                                    \
     else BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 1, MTAP_, KW_, 4);                                                             \
   } while (0)
-  const bool two_stage = wgrad_two_stage();
+  const bool two_stage = wgrad_two_stage() && !h16;   // (bf16 tensors: a 16-pixel stage is half a 16-byte unit per thread)
   if (p.form == 1) BDV_WGRAD_PL(64, 192, 2, 2, true, 32);
   else if (p.form == 2) BDV_WGRAD_PL(64, 64, 2, 2, false, 32);
   else if (p.form == 3) BDV_WGRAD_PL(256, 64, 4, 1, false, 32);
