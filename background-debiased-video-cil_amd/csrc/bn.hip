@@ -203,34 +203,44 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ 
                                                         const float4* __restrict__ res_scale, const float4* __restrict__ res_shift,
                                                         void* __restrict__ out, uint32_t* __restrict__ mask, int64_t n4, int CV) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  // n4 is a multiple of 8 (C % 32 == 0) and so is the stride: the 8 lanes of one mask word stay together
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const int c4 = (int)(i % CV);
-    const float4 v = act_ld4<ES, NT>(y, i), sc = scale[c4], sh = shift[c4];
-    float4 o;
-    o.x = fmaf(v.x, sc.x, sh.x);   // explicit: the conv loaders that apply this BatchNorm themselves (PRE) use the same expression
-    o.y = fmaf(v.y, sc.y, sh.y);
-    o.z = fmaf(v.z, sc.z, sh.z);
-    o.w = fmaf(v.w, sc.w, sh.w);
-    if (RES) {
-      float4 r = act_ld4<ES, NTR>(res, i);
-      if (res_scale != nullptr) {
-        const float4 rs = res_scale[c4], rb = res_shift[c4];
-        r.x = r.x * rs.x + rb.x; r.y = r.y * rs.y + rb.y; r.z = r.z * rs.z + rb.z; r.w = r.w * rs.w + rb.w;
+  // A thread's unit is 16 bytes = U groups of 4 channels (fp32: 1, bf16: 2).  n4 is a multiple of 8 (C % 32 == 0) and so is the
+  // stride: the 8 / U lanes of one mask word stay together.
+  constexpr int U = ActU<ES>::value;
+  constexpr int LW = 8 / U;          // lanes per mask word
+  for (int64_t iu = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; iu < n4 / U; iu += stride) {
+    float4 v[U], r[U], o[U];
+    act_ld16<ES, NT>(y, iu, v);
+    if (RES) act_ld16<ES, NTR>(res, iu, r);
+    unsigned bits = 0u;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c4 = (int)((iu * U + u) % CV);
+      const float4 sc = scale[c4], sh = shift[c4];
+      o[u].x = fmaf(v[u].x, sc.x, sh.x);   // explicit: the conv loaders that apply this BatchNorm themselves (PRE) use the same expression
+      o[u].y = fmaf(v[u].y, sc.y, sh.y);
+      o[u].z = fmaf(v[u].z, sc.z, sh.z);
+      o[u].w = fmaf(v[u].w, sc.w, sh.w);
+      if (RES) {
+        float4 q = r[u];
+        if (res_scale != nullptr) {
+          const float4 rs = res_scale[c4], rb = res_shift[c4];
+          q.x = q.x * rs.x + rb.x; q.y = q.y * rs.y + rb.y; q.z = q.z * rs.z + rb.z; q.w = q.w * rs.w + rb.w;
+        }
+        o[u].x += q.x; o[u].y += q.y; o[u].z += q.z; o[u].w += q.w;
       }
-      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-    }
-    if (RELU) {
-      if (mask != nullptr) {
-        unsigned m = nibble_gt0(o) << (4 * (threadIdx.x & 7));
-        m |= __shfl_xor(m, 1, 64);
-        m |= __shfl_xor(m, 2, 64);
-        m |= __shfl_xor(m, 4, 64);
-        if ((threadIdx.x & 7) == 0) mask[i >> 3] = m;
+      if (RELU) {
+        bits |= nibble_gt0(o[u]) << (4 * u);
+        o[u].x = fmaxf(o[u].x, 0.f); o[u].y = fmaxf(o[u].y, 0.f); o[u].z = fmaxf(o[u].z, 0.f); o[u].w = fmaxf(o[u].w, 0.f);
       }
-      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
-    act_st4<ES>(out, i, o);
+    if (RELU && mask != nullptr) {
+      unsigned m = bits << (4 * U * (threadIdx.x & (LW - 1)));
+      m |= __shfl_xor(m, 1, 64);
+      m |= __shfl_xor(m, 2, 64);
+      if (LW == 8) m |= __shfl_xor(m, 4, 64);
+      if ((threadIdx.x & (LW - 1)) == 0) mask[iu / LW] = m;
+    }
+    act_st16<ES>(out, iu, o);
   }
 }
 
@@ -305,19 +315,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
                                                             void* __restrict__ dy, int64_t n4, int CV,
                                                             const float4* __restrict__ rscale, const float4* __restrict__ rshift) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const int c4 = (int)(i % CV);
-    float4 g = act_ld4<ES, NT>(dout, i);
-    const float4 v = act_ld4<ES, NT>(y, i), mu = mean[c4], is = invstd[c4];
-    if (RELU == 1) g = apply_nibble(g, mask_nibble(mask, i));
-    if (RELU == 2) g = apply_nibble(g, derive_nibble(v, rscale[c4], rshift[c4]));
-    const float4 a = coef[c4], b = coef[CV + c4], c = coef[2 * CV + c4];
-    float4 d;
-    d.x = a.x * (g.x - b.x - ((v.x - mu.x) * is.x) * c.x);
-    d.y = a.y * (g.y - b.y - ((v.y - mu.y) * is.y) * c.y);
-    d.z = a.z * (g.z - b.z - ((v.z - mu.z) * is.z) * c.z);
-    d.w = a.w * (g.w - b.w - ((v.w - mu.w) * is.w) * c.w);
-    act_st4<ES>(dy, i, d);
+  constexpr int U = ActU<ES>::value;   // 16-byte units: U groups of 4 channels per thread (bn_apply_kernel)
+  for (int64_t iu = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; iu < n4 / U; iu += stride) {
+    float4 gg[U], vv[U], dd[U];
+    act_ld16<ES, NT>(dout, iu, gg);
+    act_ld16<ES, NT>(y, iu, vv);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = iu * U + u;
+      const int c4 = (int)(i % CV);
+      float4 g = gg[u];
+      const float4 v = vv[u], mu = mean[c4], is = invstd[c4];
+      if (RELU == 1) g = apply_nibble(g, mask_nibble(mask, i));
+      if (RELU == 2) g = apply_nibble(g, derive_nibble(v, rscale[c4], rshift[c4]));
+      const float4 a = coef[c4], b = coef[CV + c4], c = coef[2 * CV + c4];
+      float4 d;
+      d.x = a.x * (g.x - b.x - ((v.x - mu.x) * is.x) * c.x);
+      d.y = a.y * (g.y - b.y - ((v.y - mu.y) * is.y) * c.y);
+      d.z = a.z * (g.z - b.z - ((v.z - mu.z) * is.z) * c.z);
+      d.w = a.w * (g.w - b.w - ((v.w - mu.w) * is.w) * c.w);
+      dd[u] = d;
+    }
+    act_st16<ES>(dy, iu, dd);
   }
 }
 
@@ -490,10 +509,11 @@ extern "C" int bdv_bn_apply(const void* y, const float* scale, const float* shif
   BDV_REQUIRE(relu_mask == nullptr || (relu && C % 32 == 0), "bdv_bn_apply: relu_mask needs relu and C %% 32 == 0");
   BDV_REQUIRE(bdv_aligned16(y) && bdv_aligned16(out) && bdv_aligned16(scale) && bdv_aligned16(shift) &&
                   (res == nullptr || bdv_aligned16(res)), "bdv_bn_apply: alignment");
+  BDV_REQUIRE(act_dtype == BDV_ACT_F32 || C % 8 == 0, "bdv_bn_apply: bf16 tensors need C %% 8 == 0 (16-byte units)");
   const int64_t n4 = M * C / 4;
   const int CV = C / 4;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(ew_grid(n4)), blk(256);
+  const dim3 grid(ew_grid(act_dtype == BDV_ACT_BF16 ? n4 / 2 : n4)), blk(256);
   const float4 *sc = (const float4*)scale, *sh = (const float4*)shift;
   const float4 *rs = (const float4*)res_scale, *rb = (const float4*)res_shift;
 #define BDV_APPLY(...) hipLaunchKernelGGL((bn_apply_kernel<__VA_ARGS__, ES>), grid, blk, 0, s, y, sc, sh, res, rs, rb, out, relu_mask, n4, CV)
@@ -555,8 +575,9 @@ extern "C" int bdv_bn_backward(const void* dout, const uint32_t* relu_mask, cons
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(4 * FIN_LANES), 0, s, q1, q2, rows, M, C, gamma, save_invstd, dgamma,
                      dbeta, beta_acc, coef);
   BDV_LAUNCH_CHECK("bdv_bn_backward(finalize)");
+  BDV_REQUIRE(act_dtype == BDV_ACT_F32 || C % 8 == 0, "bdv_bn_backward: bf16 tensors need C %% 8 == 0 (16-byte units)");
   const int64_t n4 = M * C / 4;
-  const dim3 grid(ew_grid(n4)), blk(256);
+  const dim3 grid(ew_grid(act_dtype == BDV_ACT_BF16 ? n4 / 2 : n4)), blk(256);
   const float4 *rs4 = (const float4*)relu_scale, *rh4 = (const float4*)relu_shift;
 #define BDV_BWD_APPLY(RELU_, NT_)                                                                                              \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<RELU_, NT_, ES>), grid, blk, 0, s, dout, relu_mask, y,                               \

@@ -86,6 +86,32 @@ __device__ __forceinline__ void act_st4(void* __restrict__ base, int64_t i4, con
     reinterpret_cast<bdv_u32x2_t*>(base)[i4] = (bdv_u32x2_t){bdv_pack_bf16x2(v.x, v.y), bdv_pack_bf16x2(v.z, v.w)};
   }
 }
+// A thread's 16-byte unit of an elementwise pass: ACT_U<ES> groups of 4 consecutive elements (1 for fp32, 2 for bf16).
+template <int ES> struct ActU { static constexpr int value = ES == 2 ? 2 : 1; };
+template <int ES, bool NT = false>
+__device__ __forceinline__ void act_ld16(const void* __restrict__ base, int64_t iu, float4 (&v)[ActU<ES>::value]) {
+  if constexpr (ES == 4) {
+    v[0] = act_ld4<4, NT>(base, iu);
+  } else {
+    typedef unsigned u32x4_t_ __attribute__((ext_vector_type(4)));
+    const u32x4_t_* p = reinterpret_cast<const u32x4_t_*>(base) + iu;
+    u32x4_t_ r;
+    if constexpr (NT) r = __builtin_nontemporal_load(p);
+    else r = *p;
+    v[0] = bdv_widen_bf16x4(r.x, r.y);
+    v[1] = bdv_widen_bf16x4(r.z, r.w);
+  }
+}
+template <int ES>
+__device__ __forceinline__ void act_st16(void* __restrict__ base, int64_t iu, const float4 (&v)[ActU<ES>::value]) {
+  if constexpr (ES == 4) {
+    reinterpret_cast<float4*>(base)[iu] = v[0];
+  } else {
+    typedef unsigned u32x4_t_ __attribute__((ext_vector_type(4)));
+    reinterpret_cast<u32x4_t_*>(base)[iu] = (u32x4_t_){bdv_pack_bf16x2(v[0].x, v[0].y), bdv_pack_bf16x2(v[0].z, v[0].w),
+                                                      bdv_pack_bf16x2(v[1].x, v[1].y), bdv_pack_bf16x2(v[1].z, v[1].w)};
+  }
+}
 // host-side dispatch on bdv act_dtype: BDV_ACT_SWITCH(dt, ES, launch<ES>(...))
 #define BDV_ACT_SWITCH(dt, ES, ...)  \
   do {                               \
