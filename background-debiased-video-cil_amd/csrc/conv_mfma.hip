@@ -2877,7 +2877,11 @@ int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride, int pieces = 3,
     if (nk >= 16 || nk <= 2) return 0;
     return -1;
   }
-  static const bool small_tiles = getenv("BDVCIL_DGRAD_64X128") != nullptr && atoi(getenv("BDVCIL_DGRAD_64X128")) != 0;
+  static const int small_mode = getenv("BDVCIL_DGRAD_64X128") != nullptr ? atoi(getenv("BDVCIL_DGRAD_64X128")) : 0;
+  const bool small_tiles = small_mode == 1;
+  // 2: only the conv1 dgrads of layer 1 / 2 (K <= 128: the sites furthest above their HBM time), 3: layer 1 only -- three alternating
+  // runs each: 591.0 (off), 591.3 (2), 592.6 (3) clips/s on average, i.e. level within the run-to-run spread: tuning switches only
+  if ((small_mode == 2 && shifted && taps == 1 && nk <= 4) || (small_mode == 3 && shifted && taps == 1 && nk <= 2)) return ncols % 128 == 0 ? 4 : -1;
   if (ncols % 256 != 0) return taps > 1 && stride == 1 ? 1 : (small_tiles && taps == 1 && stride == 1 && nk >= 16 ? 4 : -1);
   if (stride == 2 && taps > 1) return 0;
   if (small_tiles && shifted && taps == 1) return 4;
