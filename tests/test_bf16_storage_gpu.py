@@ -311,3 +311,24 @@ def test_kd_step_on_bf16_features(dev, bf16_mode):
     assert abs(ol['loss'].item() - rl['loss'].item()) <= 5e-2 * max(1.0, abs(rl['loss'].item()))
     for p in mod.parameters():
         assert p.grad is None or (p.grad.dtype == torch.float32 and bool(torch.isfinite(p.grad).all()))
+
+
+def test_task_loop_runs_in_bf16_storage(tmp_path, dev, bf16_mode):
+    """Two tasks of the CIL loop (feature KD on hooked bf16 stage outputs, exemplar selection and class means from the fp32
+    representations, the files of libs/cil/cil.py:28-375) with bf16-stored activations: finite losses, every file of a run."""
+    import os
+
+    import numpy as np
+    from test_task_loop_gpu import BUDGET, TASKS, _config, _loop
+    cfg = _config(tmp_path, ending_task=1, num_epochs_per_task=1)
+    loop = _loop(cfg)
+    hist = loop.train()
+    assert len(hist) == 2 and all(np.isfinite(h['train_loss']).all() for h in hist)
+    work = cfg['work_dir']
+    for t in range(2):
+        assert os.path.exists(os.path.join(work, 'ckpt', f'ckpt_task_{t}.pt'))
+        assert os.path.exists(os.path.join(work, 'exemplar', f'exemplar_task_{t}.txt'))
+    lines = open(os.path.join(work, 'exemplar', 'exemplar_task_1.txt')).read().split('\n')
+    assert len([l for l in lines if l.strip()]) == BUDGET * len(TASKS[1])          # the new classes of task 1
+    sd = torch.load(os.path.join(work, 'ckpt', 'ckpt_task_1.pt'), weights_only=True)
+    assert all(v.dtype in (torch.float32, torch.int64) for v in sd.values())       # checkpoints are the same fp32 state_dicts

@@ -32,6 +32,20 @@ def test_c_abi_exports_every_declared_symbol():
     assert bd._lib.lib().bdv_abi_version() == bd._lib.ABI_VERSION
 
 
+def test_conv_geom_mirror_matches_the_header():
+    """``_lib.ConvGeom`` (ctypes) lists the fields of ``bdv_conv_geom`` in the header's order, all int32: a field added on one side
+    only would shift every later one silently."""
+    hdr = open(os.path.join(ROOT, 'include', 'bdvcil_hip.h')).read()
+    body = re.search(r'typedef struct bdv_conv_geom \{(.*?)\} bdv_conv_geom;', hdr, re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = []
+    for decl in re.findall(r'int32_t\s+([^;]+);', body):
+        fields += [n.strip() for n in decl.split(',')]
+    assert fields == [n for n, _ in bd._lib.ConvGeom._fields_]
+    assert all(t is ctypes.c_int32 for _, t in bd._lib.ConvGeom._fields_)
+    assert ctypes.sizeof(bd._lib.ConvGeom) == 4 * len(fields)
+
+
 def test_stale_library_is_refused(monkeypatch):
     """The binding loads only a library built from the sources next to it (bdv_source_hash == sha256 of csrc + header)."""
     L = bd._lib
