@@ -16,7 +16,17 @@ Import as ``bdvcil_amd`` (see ``bdvcil_amd.py`` at the repo root).  Layout:
 * ``resnet3d``     I3D-ResNet50 (ResNet3d / I3DHead / Recognizer3D) on the same kernels (temporal convs as k x 1 convs)
 * ``task_loop``    the CIL task loop (CILTrainer + CILDataModule bookkeeping, same files on disk)
 """
-from . import _lib, kernels  # noqa: F401
+import os as _os
+
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue run in order.  The
+# step uses the main stream, the weight-gradient side stream, a pinned-staging copy stream and -- under torch.distributed -- the
+# reducer's communication stream plus RCCL's own: with four queues the side stream then shares one, and the overlap of the weight
+# gradients with the BatchNorm / dgrad chain is lost (one MI355X, the RCCL path as a one-rank group: 541.8 clips/s against 573.1
+# without the process group; with eight queues 571.3 against 574.6).  Must be in the environment before the HIP runtime starts:
+# import this package (or set it) before the first torch.cuda call.  An explicit setting of the caller's wins.
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+from . import _lib, kernels  # noqa: F401,E402
 from .registry import (BACKBONES, HEADS, LOSSES, OPTIMIZER_BUILDERS, RECOGNIZERS, Registry, build_backbone,  # noqa: F401
                        build_head, build_loss, build_model)
 from .resnet_tsm import Nhwc4Frames, ResNetTSM, TemporalShift  # noqa: F401

@@ -22,6 +22,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# before anything starts the HIP runtime (bdvcil_amd/__init__.py says why): enough hardware queues for the streams of the
+# distributed path, so that the weight-gradient stream keeps a queue of its own
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -326,7 +329,7 @@ def main():
     reducer = None
     if use_dist:
         bd.broadcast_parameters(model)
-        reducer = bd.GradAllReducer(model, bucket_cap_mb=25.0)
+        reducer = bd.GradAllReducer(model, bucket_cap_mb=float(os.environ.get('BDVCIL_BUCKET_MB', '25')))
     opt = bd.build_optimizer(model, dict(type='SGD', constructor='CILTSMOptimizerConstructorImprovised',
                                          paramwise_cfg=dict(fc_lr_scale_factor=5.0), lr=0.01, momentum=0.9, weight_decay=1e-4))
     engine = bd.TrainEngine(model, opt, grad_clip=1.0 if cil else None, reducer=reducer)
