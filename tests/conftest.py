@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The CPU oracle (torch CPU ops) is what most of the -m gpu suite's wall time goes to.  torch sizes its thread pool by the
+    # host's core count (256 on a GPU box), the box grants a one-GPU job about 16 cores: left alone, the pool is oversubscribed
+    # 16-fold and the suite's time swings between 5 and 13 minutes with the host's load.  Same cap as bench.py's cpu_baseline.
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope='session')
