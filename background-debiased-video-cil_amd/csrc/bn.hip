@@ -513,7 +513,7 @@ extern "C" int bdv_bn_apply(const void* y, const float* scale, const float* shif
   const int64_t n4 = M * C / 4;
   const int CV = C / 4;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(ew_grid(act_dtype == BDV_ACT_BF16 ? n4 / 2 : n4)), blk(256);
+  const dim3 grid(ew_grid(act_dtype == BDV_ACT_BF16 ? n4 / 2 : n4 / BDV_F32_UNITS)), blk(256);
   const float4 *sc = (const float4*)scale, *sh = (const float4*)shift;
   const float4 *rs = (const float4*)res_scale, *rb = (const float4*)res_shift;
 #define BDV_APPLY(...) hipLaunchKernelGGL((bn_apply_kernel<__VA_ARGS__, ES>), grid, blk, 0, s, y, sc, sh, res, rs, rb, out, relu_mask, n4, CV)
@@ -577,7 +577,7 @@ extern "C" int bdv_bn_backward(const void* dout, const uint32_t* relu_mask, cons
   BDV_LAUNCH_CHECK("bdv_bn_backward(finalize)");
   BDV_REQUIRE(act_dtype == BDV_ACT_F32 || C % 8 == 0, "bdv_bn_backward: bf16 tensors need C %% 8 == 0 (16-byte units)");
   const int64_t n4 = M * C / 4;
-  const dim3 grid(ew_grid(act_dtype == BDV_ACT_BF16 ? n4 / 2 : n4)), blk(256);
+  const dim3 grid(ew_grid(act_dtype == BDV_ACT_BF16 ? n4 / 2 : n4 / BDV_F32_UNITS)), blk(256);
   const float4 *rs4 = (const float4*)relu_scale, *rh4 = (const float4*)relu_shift;
 #define BDV_BWD_APPLY(RELU_, NT_)                                                                                              \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<RELU_, NT_, ES>), grid, blk, 0, s, dout, relu_mask, y,                               \

@@ -87,11 +87,18 @@ __device__ __forceinline__ void act_st4(void* __restrict__ base, int64_t i4, con
   }
 }
 // A thread's 16-byte unit of an elementwise pass: ACT_U<ES> groups of 4 consecutive elements (1 for fp32, 2 for bf16).
-template <int ES> struct ActU { static constexpr int value = ES == 2 ? 2 : 1; };
+#ifndef BDV_F32_UNITS
+#define BDV_F32_UNITS 1      // channel groups (float4) per lane and iteration in the fp32 elementwise passes.  2 was measured
+                             // (tools/bench_bn.py, two libraries in one call): apply passes 6.49 -> 6.62 ms, backward 12.17 -> 13.11 ms
+                             // over the R50 sizes, 590.9 -> 572.2 clips/s in the step; only the 822 MB layer-1 pass with a residual,
+                             // which misses the Infinity Cache entirely, gained (613 -> 539 us)
+#endif
+template <int ES> struct ActU { static constexpr int value = ES == 2 ? 2 : BDV_F32_UNITS; };
 template <int ES, bool NT = false>
 __device__ __forceinline__ void act_ld16(const void* __restrict__ base, int64_t iu, float4 (&v)[ActU<ES>::value]) {
   if constexpr (ES == 4) {
-    v[0] = act_ld4<4, NT>(base, iu);
+#pragma unroll
+    for (int u = 0; u < ActU<4>::value; ++u) v[u] = act_ld4<4, NT>(base, iu * ActU<4>::value + u);
   } else {
     typedef unsigned u32x4_t_ __attribute__((ext_vector_type(4)));
     const u32x4_t_* p = reinterpret_cast<const u32x4_t_*>(base) + iu;
@@ -105,7 +112,8 @@ __device__ __forceinline__ void act_ld16(const void* __restrict__ base, int64_t 
 template <int ES>
 __device__ __forceinline__ void act_st16(void* __restrict__ base, int64_t iu, const float4 (&v)[ActU<ES>::value]) {
   if constexpr (ES == 4) {
-    reinterpret_cast<float4*>(base)[iu] = v[0];
+#pragma unroll
+    for (int u = 0; u < ActU<4>::value; ++u) reinterpret_cast<float4*>(base)[iu * ActU<4>::value + u] = v[u];
   } else {
     typedef unsigned u32x4_t_ __attribute__((ext_vector_type(4)));
     reinterpret_cast<u32x4_t_*>(base)[iu] = (u32x4_t_){bdv_pack_bf16x2(v[0].x, v[0].y), bdv_pack_bf16x2(v[0].z, v[0].w),
