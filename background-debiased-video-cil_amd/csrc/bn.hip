@@ -438,7 +438,12 @@ __global__ __launch_bounds__(256) void add_kernel(const void* __restrict__ a, co
 
 int ew_grid(int64_t n4) {
   int64_t b = (n4 + 255) / 256;
-  if (b > 4096) b = 4096;
+  // Blocks per launch of the grid-stride passes.  A cap of 4096 blocks (16 MB between a thread's successive accesses) cost the
+  // passes over the large tensors a quarter of their bandwidth: the 822 MB layer-1 apply pass with a residual 548 us (4.5 TB/s)
+  // capped at 4096, 454 us at 65536, 416 us (5.9 TB/s) with one unit per thread; all apply passes of a step 6.00 -> 5.05 ms,
+  // backward 11.93 -> 11.21 ms (tools/bench_bn.py), 589.4 -> 601.9 clips/s in the step (two alternating pairs, one box).
+  static const int cap = getenv("BDVCIL_EW_BLOCKS") ? atoi(getenv("BDVCIL_EW_BLOCKS")) : (1 << 20);
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }

@@ -660,7 +660,7 @@ extern "C" int bdv_kd_mse_bwd(const void* cur, const void* prev, const float* gs
   BDV_REQUIRE(bdv_aligned16(cur) && bdv_aligned16(prev) && bdv_aligned16(dcur), "bdv_kd_mse_bwd: alignment");
   const int64_t n4 = numel / 4;
   int64_t nb = (n4 + 255) / 256;
-  if (nb > 4096) nb = 4096;
+  if (nb > (1 << 20)) nb = 1 << 20;
   BDV_ACT_SWITCH(act_dtype, ES, hipLaunchKernelGGL((kd_mse_bwd_kernel<ES>), dim3((int)nb), dim3(256), 0, HL_STREAM, cur, prev, gscale_dev,
                      gscale_host * 2.f / (float)numel, dcur, n4));
   BDV_LAUNCH_CHECK("bdv_kd_mse_bwd");

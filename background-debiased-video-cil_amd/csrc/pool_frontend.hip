@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void crop_normalize_kernel(const uint8_t* __re
 
 int ew_grid(int64_t n) {
   int64_t b = (n + 255) / 256;
-  if (b > 8192) b = 8192;
+  if (b > (1 << 20)) b = 1 << 20;   // (one unit per thread: see ew_grid in bn.hip)
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -309,7 +309,7 @@ extern "C" int bdv_maxpool_t2_fwd(const float* x, float* out, uint32_t* sel, int
   BDV_REQUIRE(bdv_aligned16(x) && bdv_aligned16(out), "bdv_maxpool_t2_fwd: alignment");
   const int64_t n4 = frames_out * frame_elems / 4;
   int64_t blocks = (n4 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > (1 << 20)) blocks = 1 << 20;
   hipLaunchKernelGGL(maxpool_t2_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)out, sel,
                      frame_elems / 4, n4);
   BDV_LAUNCH_CHECK("bdv_maxpool_t2_fwd");
@@ -322,7 +322,7 @@ extern "C" int bdv_maxpool_t2_bwd(const float* dout, const uint32_t* sel, float*
   BDV_REQUIRE(bdv_aligned16(dout) && bdv_aligned16(dx), "bdv_maxpool_t2_bwd: alignment");
   const int64_t n4 = frames_out * frame_elems / 4;
   int64_t blocks = (n4 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > (1 << 20)) blocks = 1 << 20;
   hipLaunchKernelGGL(maxpool_t2_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)dout, sel, (float4*)dx,
                      frame_elems / 4, n4);
   BDV_LAUNCH_CHECK("bdv_maxpool_t2_bwd");
