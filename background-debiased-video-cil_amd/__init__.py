@@ -24,7 +24,19 @@ import os as _os
 # gradients with the BatchNorm / dgrad chain is lost (one MI355X, the RCCL path as a one-rank group: 541.8 clips/s against 573.1
 # without the process group; with eight queues 571.3 against 574.6).  Must be in the environment before the HIP runtime starts:
 # import this package (or set it) before the first torch.cuda call.  An explicit setting of the caller's wins.
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+if 'GPU_MAX_HW_QUEUES' not in _os.environ:
+    _os.environ['GPU_MAX_HW_QUEUES'] = '8'
+    import sys as _sys
+    _torch = _sys.modules.get('torch')
+    if _torch is not None and _torch.cuda.is_initialized():
+        # too late for this process: the runtime read its environment when it started (a caller that touched torch.cuda first, or a
+        # profiler that preloads the runtime).  Not fatal -- only the stream overlap of the distributed path is at stake.
+        import warnings as _warnings
+        _warnings.warn('bdvcil_amd: the HIP runtime was initialised before this package was imported, so GPU_MAX_HW_QUEUES=8 cannot '
+                       'take effect; under torch.distributed the weight-gradient stream then shares a hardware queue (about 5 % of '
+                       'step time). Export GPU_MAX_HW_QUEUES=8 or import bdvcil_amd before the first torch.cuda call.',
+                       RuntimeWarning, stacklevel=2)
+from .kernels import bump_weight_epoch  # noqa: F401,E402
 
 from . import _lib, kernels  # noqa: F401,E402
 from .registry import (BACKBONES, HEADS, LOSSES, OPTIMIZER_BUILDERS, RECOGNIZERS, Registry, build_backbone,  # noqa: F401

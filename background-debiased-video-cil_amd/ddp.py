@@ -45,11 +45,18 @@ class _Bucket:
         self.pending = 0
         self.work = None
         self.event = None
+        self.held = None            # the gradients the pack copy reads on the communication stream, kept until finish() has joined it
+        self.no_grad: List[bool] = []
+        self.flags: Optional[torch.Tensor] = None
 
     def ensure(self):
         p0 = self.params[0]
         if self.flat is None or self.flat.device != p0.device:
-            self.flat = torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
+            # payload, then one "a gradient arrived on this rank" flag per parameter: summed with the gradients, so that every rank
+            # can tell a parameter NO rank used (its .grad stays None, the optimizer skips it everywhere) from one that only this rank
+            # did not use (the other ranks' sum is its gradient here too)
+            self.flat = torch.zeros(self.numel + len(self.params), dtype=p0.dtype, device=p0.device)
+            self.flags = self.flat[self.numel:]
             self.views, off = [], 0
             for p in self.params:
                 # a view with the parameter's own (dense, possibly channels_last) strides
@@ -94,7 +101,25 @@ class GradAllReducer:
                 self._index[p] = bi
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._comm_stream = None
+        self.timing = False         # bench.py: HIP events around the waits of finish() -> exposed_ms()
+        self._exposed = []
         self.reset()
+
+    def describe(self) -> dict:
+        """What the exchange looks like from this rank: filled from the communicator, not from the launcher's environment."""
+        on = dist.is_available() and dist.is_initialized()
+        return dict(ranks=dist.get_world_size(self.group) if on else 1, backend=dist.get_backend(self.group) if on else None,
+                    buckets=len(self.buckets), payload_mb=round(sum(b.numel for b in self.buckets) * 4 / 2 ** 20, 2),
+                    bucket_mb=[round(b.numel * 4 / 2 ** 20, 2) for b in self.buckets])
+
+    def exposed_ms(self):
+        """Mean time per step the compute stream spent blocked in finish() waiting for the collectives (None: not timed / CPU)."""
+        if not self._exposed:
+            return None
+        if isinstance(self._exposed[0], float):             # CPU tensors (gloo tests): host wall clock around the waits
+            return sum(self._exposed) / len(self._exposed)
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
 
     @property
     def grad_scale(self) -> float:
@@ -137,9 +162,15 @@ class GradAllReducer:
             b.no_grad = [p.grad is None for p in b.params]
             grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
             torch._foreach_copy_(b.views, grads)                      # pack (copy plumbing, no arithmetic)
-            if on_gpu:
-                for g in grads:
-                    g.record_stream(self._comm_stream)
+            if getattr(b, '_flag_pattern', None) != b.no_grad:        # (device copy of the pattern: rebuilt only when it changes)
+                b._flag_pattern = list(b.no_grad)
+                b._flag_src = torch.tensor([0.0 if s else 1.0 for s in b.no_grad], dtype=b.flat.dtype).to(b.flat.device)
+            b.flags.copy_(b._flag_src)
+            # The gradients were allocated on the compute stream and are read here on the communication stream.  They stay
+            # referenced (p.grad, and this list) until finish() has made the compute stream wait for this bucket; record_stream()
+            # instead would keep every one of these blocks out of the allocator's pool for a step (functional.SIDE_LAG says what
+            # that costs: 115 GB reserved for 24 GB of tensors).
+            b.held = grads
             if self.world > 1 or (_FORCE and dist.is_initialized()):
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if on_gpu:
@@ -147,15 +178,36 @@ class GradAllReducer:
                 b.event.record(self._comm_stream)
 
     def finish(self):
-        """Wait for all buckets; afterwards ``p.grad`` aliases the reduced (summed) bucket slices."""
+        """Wait for all buckets; afterwards ``p.grad`` aliases the reduced (summed) bucket slices.  A parameter that received no
+        gradient on ANY rank keeps ``.grad = None``; one that only this rank did not use gets the other ranks' sum, as under torch's
+        DistributedDataParallel (the flags travel in the bucket, so every rank decides alike)."""
         for b in self.buckets:
             if b.pending != 0:
                 # parameters that received no gradient this step (unused / frozen late): reduce what we have
                 self._launch(b)
+        timed = bool(self.timing and self.buckets and self.buckets[0].flat is not None)
+        on_gpu = timed and self.buckets[0].flat.is_cuda
+        if on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        elif timed:
+            import time
+            t0 = time.perf_counter()
+        for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
             if b.event is not None:
                 torch.cuda.current_stream().wait_event(b.event)
-            for p, v, skipped in zip(b.params, b.views, getattr(b, 'no_grad', None) or [False] * len(b.params)):
-                p.grad = None if skipped else v
+        if on_gpu:
+            e1.record()
+            self._exposed.append((e0, e1))
+        elif timed:
+            self._exposed.append((time.perf_counter() - t0) * 1e3)
+        for b in self.buckets:
+            b.held = None       # the compute stream is ordered behind the pack copies now
+            used_elsewhere = None
+            if any(b.no_grad) and self.world > 1:
+                used_elsewhere = (b.flags > 0).tolist()     # rare path (a parameter unused on this rank): one small read-back
+            for i, (p, v, skipped) in enumerate(zip(b.params, b.views, b.no_grad or [False] * len(b.params))):
+                p.grad = None if (skipped and not (used_elsewhere and used_elsewhere[i])) else v
         self.reset()

@@ -157,6 +157,7 @@ def wgrad_overlapped(dy: torch.Tensor, inp: torch.Tensor, geom, pre_bn=None) -> 
     ready = torch.cuda.Event()
     ready.record(main)
     side.wait_event(ready)
+    raw = inp                       # what the side stream READS (allocated on main): held / registered below, also when `inp` is rebound
     with torch.cuda.stream(side):
         if recompute:               # the activation exists only for the duration of this weight gradient
             inp = K.bn_apply(inp, pre_bn[0], pre_bn[1], None, True)
@@ -170,12 +171,12 @@ def wgrad_overlapped(dy: torch.Tensor, inp: torch.Tensor, geom, pre_bn=None) -> 
         done.record(side)
     if SIDE_LAG > 0:
         held = _SIDE['held'].setdefault(idx, _collections.deque())
-        held.append((done, (dy, inp)))
+        held.append((done, (dy, raw, inp)))
         while len(held) > SIDE_LAG:
             ev, _ = held.popleft()
             main.wait_event(ev)     # (long finished: the side stream runs beside the main chain, not behind it)
     else:
-        for t in (dy, inp, dw):
+        for t in (dy, raw, inp, dw):
             t.record_stream(side)
     _SIDE['pending'][idx] = done
     return dw

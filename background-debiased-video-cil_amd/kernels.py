@@ -170,7 +170,18 @@ def set_conv_arith(mode: str):
 import weakref as _weakref
 
 WEIGHT_EPOCH = 0
-_PLANES = {}        # id(base tensor) -> [weakref, (data_ptr, version, epoch), uint8 buffer holding both layouts]
+_PLANES = {}        # id(base tensor) -> [weakref, (data_ptr, version, epoch), uint8 buffer holding both layouts, view, geometry, checksum]
+# A write that torch's version counter does not see -- ``p.data.mul_()``, ``p.data.copy_()``, ``dist.broadcast(p.data)``, any kernel
+# given ``p.data_ptr()`` -- leaves the stamp unchanged and the cached planes STALE: the convolutions would then run on the old
+# weights without any error.  Such writers must call ``bump_weight_epoch()`` ("Weights written behind torch's
+# back"); the writers inside this package (FusedSGD.step, broadcast_parameters) do.  BDVCIL_CHECK_PLANES=1 is the debugging aid for
+# plugin code: every ``weight_planes`` hit then compares a checksum of the weight's bits with the one taken when the planes were
+# cut (one device reduction and one host synchronisation per convolution: slow, never for timing) and raises on a mismatch.
+CHECK_PLANES = _os.environ.get('BDVCIL_CHECK_PLANES', '0') != '0'
+
+
+def _weight_checksum(w: torch.Tensor) -> int:
+    return int(w.contiguous().view(torch.int32).to(torch.int64).sum().item())
 USE_PL = _os.environ.get('BDVCIL_PL', '1') != '0'       # 0: the round-1 bf16-piece kernels (operands split in the K loop)
 USE_PL_WGRAD = _os.environ.get('BDVCIL_PL_WGRAD', '1') != '0'
 
@@ -220,8 +231,14 @@ def weight_planes(w: torch.Tensor, g: ConvGeom):
               'bdv_conv_split_weights')
         ref = _weakref.ref(base, lambda _r, k=key: _PLANES.pop(k, None))
         # how to rebuild the view and the geometry without holding the parameter alive (refresh_weight_planes)
-        ent = [ref, stamp, buf, (tuple(w.shape), tuple(w.stride()), w.storage_offset()), (g.R, g.S, g.Cin, g.Cout)]
+        ent = [ref, stamp, buf, (tuple(w.shape), tuple(w.stride()), w.storage_offset()), (g.R, g.S, g.Cin, g.Cout),
+               _weight_checksum(w) if CHECK_PLANES else None]
         _PLANES[key] = ent
+    elif CHECK_PLANES and ent[5] is not None and _weight_checksum(w) != ent[5]:
+        raise RuntimeError(
+            'stale weight planes: a convolution weight of shape %s was changed without torch noticing (a write through `.data`, a '
+            'raw-pointer kernel, dist.broadcast(p.data), ...) after its bf16 planes were cut, so fprop / dgrad would run on the OLD '
+            'weights.  Call bdvcil_amd.bump_weight_epoch() after such a write (INTEGRATION.md).' % (tuple(w.shape),))
     return ent[2][:nbytes], ent[2][nbytes:]
 
 
@@ -254,6 +271,8 @@ def refresh_weight_planes(stream: Optional[torch.cuda.Stream] = None) -> int:
                 check(lib().bdv_conv_split_weights(_p(w), ctypes.byref(g), _p(buf[:nbytes]), _p(buf[nbytes:]), _stream()),
                       'bdv_conv_split_weights')
                 ent[1] = _plane_stamp(w, base)
+                if CHECK_PLANES:
+                    ent[5] = _weight_checksum(w)
                 n += 1
             if st != cur:
                 ev = torch.cuda.Event()

@@ -141,6 +141,10 @@ class _Stem3dFn(torch.autograd.Function):
         Tp = (To - 1) // 2 + 1
         even = a.view(B, To, g.Ho, g.Wo, Cout)[:, ::2].contiguous().view(B * Tp, g.Ho, g.Wo, Cout)
         p, pidx = K.maxpool_fwd(even)
+        if Fn.RELU_MASK_TAP is not None and mask is not None:      # tests: the stem's ReLU sign bits / pool1's arg-max codes
+            Fn.RELU_MASK_TAP.append((tuple(y.shape), mask))
+        if Fn.POOL_IDX_TAP is not None:
+            Fn.POOL_IDX_TAP.append(pidx)
         ctx.meta = (g, B, To, Tp, kt, fused)
         ctx.bn_training = training
         if save:
@@ -175,6 +179,8 @@ class _PoolT2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         out, sel = K.maxpool_t2_fwd(x.contiguous())
+        if Fn.POOL_IDX_TAP is not None:                             # tests: which frame of each pair pool2 took
+            Fn.POOL_IDX_TAP.append(sel)
         ctx.save_for_backward(sel)
         return out
 

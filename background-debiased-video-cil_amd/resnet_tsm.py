@@ -158,6 +158,10 @@ class ResStage(nn.Sequential):
         return True
 
     def forward(self, x):
+        # links to the neighbouring stages: set by the backbone for this call only, taken (and cleared) before anything can fail or
+        # fall back, so that a stage never keeps the producer's saved tensors alive (nor hands them to a deepcopy of the model)
+        in_link, out_link = getattr(self, '_in_link', None), getattr(self, '_out_link', None)
+        self._in_link = self._out_link = None
         if not Fn.FUSE_STAGE or len(self) < 2 or not self._blocks_are_plain():
             return super().forward(x)
         xh = Fn.nchw_view_to_nhwc(x)
@@ -169,9 +173,6 @@ class ResStage(nn.Sequential):
         flags = {b.unit_bns[0].training for b in blocks}
         if len(flags) != 1:
             return super().forward(x)
-        # links to the neighbouring stages (set by the backbone's forward for this call only; see Fn.StageLink)
-        in_link, out_link = getattr(self, '_in_link', None), getattr(self, '_out_link', None)
-        self._in_link = self._out_link = None
         out = Fn.ResStageFn.apply(xh, blocks, flags.pop(), in_link, out_link, *params)
         return Fn.nhwc_to_nchw_view(out)
 
@@ -199,6 +200,19 @@ class Bottleneck(_ResBlock):
         self.conv3 = ConvModule(planes, planes * 4, 1, 1, 0, act=False)
         self.downsample = downsample
         self._finalize()
+
+
+def _has_hooks(m: nn.Module, pre: bool) -> bool:
+    """pre=False: anything that observes the module's OUTPUT or its gradient; pre=True: anything that observes its INPUT."""
+    if pre:
+        return bool(m._forward_pre_hooks or getattr(m, '_backward_pre_hooks', None))
+    return bool(m._forward_hooks or m._backward_hooks or getattr(m, '_backward_pre_hooks', None))
+
+
+def _global_module_hooks() -> bool:
+    mod = torch.nn.modules.module
+    return any(bool(getattr(mod, n, None)) for n in ('_global_forward_hooks', '_global_forward_pre_hooks', '_global_backward_hooks',
+                                                      '_global_backward_pre_hooks'))
 
 
 @BACKBONES.register_module()
@@ -313,19 +327,26 @@ class ResNetTSM(nn.Module):
         p = Fn.StemFn.apply(x4, stem.conv.weight, stem.bn.weight, stem.bn.bias, stem.bn, training)
         out = Fn.nhwc_to_nchw_view(p)
         link = None
-        for i, name in enumerate(self.res_layers):
-            stage = getattr(self, name)
+        stages = [getattr(self, name) for name in self.res_layers]
+        for i, stage in enumerate(stages):
             if isinstance(stage, ResStage):
                 stage._in_link = link
-                # this stage's output is private to the next stage unless something hooks the stage module (OutputHook for the
-                # feature-KD terms does): only then may the next stage's backward take BatchNorm statistics for this one
-                private = (i + 1 < len(self.res_layers) and not stage._forward_hooks and not stage._backward_hooks
-                           and not torch.nn.modules.module._global_forward_hooks)
+                # this stage's output is private to the next stage unless something can see it on the way: a forward / backward hook
+                # on the stage module (OutputHook for the feature-KD terms), a pre-hook of the next stage (which receives the same
+                # tensor), or a global module hook.  Only a private output lets the next stage's backward take BatchNorm statistics
+                # for this one.
+                nxt = stages[i + 1] if i + 1 < len(stages) else None
+                private = (nxt is not None and isinstance(nxt, ResStage) and not _has_hooks(stage, pre=False) and not _has_hooks(nxt, pre=True)
+                           and not _global_module_hooks())
                 link = Fn.StageLink() if (training and private) else None
                 stage._out_link = link
             else:
                 link = None
-            out = stage(out)
+            try:
+                out = stage(out)
+            finally:
+                if isinstance(stage, ResStage):
+                    stage._in_link = stage._out_link = None      # (a stage that raised or was replaced never took them)
         return out
 
     def train(self, mode=True):

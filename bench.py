@@ -230,20 +230,43 @@ def self_launch(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def dist_record(reducer, world):
+    """What proves an N > 1 record: the communicator's own view (ranks, backend, buckets, payload) -- not WORLD_SIZE -- and the time
+    per step the compute stream spent blocked in ``GradAllReducer.finish()`` (HIP events around its waits; 0 when the collectives hid
+    under backward).  Replaces the implicit DDP reducer of libs/cil/cil.py:704-709."""
+    if reducer is None:
+        return {'parallelism': f'dp{world}'}
+    d = reducer.describe()
+    exposed = reducer.exposed_ms()
+    return {'parallelism': f'dp{d["ranks"]}', 'rccl': d, 'allreduce_exposed_ms': None if exposed is None else round(exposed, 4)}
+
+
 def selftest_cpu(args, world, rank):
     """What the ranks started by ``self_launch`` do in the CPU test of the launcher: the rendezvous, the barrier-bracketed
     timing with the MAX over ranks, and rank 0 printing the one line -- over gloo, with no GPU and no kernels."""
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bdvcil_amd as bd
+    torch.manual_seed(0)
+    toy = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8))
+    bd.broadcast_parameters(toy)
+    reducer = bd.GradAllReducer(toy, bucket_cap_mb=0.001)
+    reducer.timing = True
     dist.barrier()
     t0 = time.perf_counter()
     x = torch.ones(4) * (rank + 1)
     dist.all_reduce(x)
+    for _ in range(args.steps):                  # the reducer's own path over gloo: bucketed all-reduce + finish()
+        for p in toy.parameters():
+            p.grad = None
+        toy(torch.randn(4, 64)).sum().backward()
+        reducer.finish()
     dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
         print(json.dumps({'metric': 'launcher selftest', 'value': float(x[0]), 'n_gpus': world, 'steps': args.steps,
-                          'warmup': args.warmup, 'ms_per_step': float(t) * 1e3}), flush=True)
+                          'warmup': args.warmup, 'ms_per_step': float(t) * 1e3,
+                          'config': dist_record(reducer, world)}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     return 0
@@ -330,6 +353,7 @@ def main():
     if use_dist:
         bd.broadcast_parameters(model)
         reducer = bd.GradAllReducer(model, bucket_cap_mb=float(os.environ.get('BDVCIL_BUCKET_MB', '25')))
+        reducer.timing = True
     opt = bd.build_optimizer(model, dict(type='SGD', constructor='CILTSMOptimizerConstructorImprovised',
                                          paramwise_cfg=dict(fc_lr_scale_factor=5.0), lr=0.01, momentum=0.9, weight_decay=1e-4))
     engine = bd.TrainEngine(model, opt, grad_clip=1.0 if cil else None, reducer=reducer)
@@ -455,9 +479,12 @@ def main():
                                       'head and loss' if args.arith == 'bf16' else
                                       'fp32 tensors and results; conv products on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)'),
                        'conv_arith': args.arith,
-                       'clips_per_gpu': args.batch, 'global_batch': args.batch * world, 'parallelism': f'dp{world}',
+                       'clips_per_gpu': args.batch, 'global_batch': args.batch * world,
                        'final_loss': round(loss_val, 5)},
         }
+        res['config'].update(dist_record(reducer, world))
+        if reducer is not None:
+            res['n_gpus'] = reducer.describe()['ranks'] if world > 1 else world      # the communicator's count, not the launcher's
         ms = torch.cuda.memory_stats(dev)
         res['config']['hbm'] = {'peak_allocated_gb': round(ms.get('allocated_bytes.all.peak', 0) / 2**30, 2),
                                 'peak_reserved_gb': round(ms.get('reserved_bytes.all.peak', 0) / 2**30, 2),

@@ -33,8 +33,9 @@ def _err(a, b):
     return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
 
 
-@pytest.mark.parametrize('site', SITES, ids=lambda s: 'x'.join(map(str, s)))
-def test_site_parity_full_size(site, dev):
+def check_site(site, N, dev, modes=('bf16x3', 'f32mfma'), T=8):
+    """fprop / dgrad (+ residual gradient and ReLU mask) / wgrad of one conv site at N frames against torch CPU fp32 (and fp64
+    samples for the weight gradient), in every arithmetic of ``modes``.  Shared with tests/test_baseline_sizes_gpu.py."""
     from bdvcil_amd import kernels as K
     Cin, Cout, k, st, H, shift = site
     pad = k // 2
@@ -44,7 +45,7 @@ def test_site_parity_full_size(site, dev):
     fold = Cin // 8 if shift else 0
     x.requires_grad_(True)
     w.requires_grad_(True)
-    xs = temporal_shift(x, 8, 8) if shift else x
+    xs = temporal_shift(x, T, 8) if shift else x
     y = F.conv2d(xs, w, stride=st, padding=pad)
     dy = torch.randn(y.shape, generator=gen)
     y.backward(dy)
@@ -59,7 +60,7 @@ def test_site_parity_full_size(site, dev):
         xd, wd, cin_k = x4.to(dev), w4.to(dev), 4
     else:
         xd, wd, cin_k = x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), Cin
-    g = K.make_geom(N, H, H, cin_k, Cout, k, k, st, pad, 8 if shift else 1, fold)
+    g = K.make_geom(N, H, H, cin_k, Cout, k, k, st, pad, T if shift else 1, fold)
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev)
     add = mask_bits = None
     if not stem:        # residual gradient + ReLU mask of the block output, as the conv1 dgrad of a block sees them
@@ -83,7 +84,7 @@ def test_site_parity_full_size(site, dev):
         win = xs_p[:, ci[q], rr[q]:rr[q] + st * (Ho - 1) + 1:st, ss[q]:ss[q] + st * (Ho - 1) + 1:st]
         dw_smp[q] = (win * dyd64[:, co[q]]).sum()
     scale_dw = dw_ref.abs().max().item()
-    for mode in ('bf16x3', 'f32mfma'):
+    for mode in modes:
         prev = K.set_conv_arith(mode)
         try:
             yo = K.conv_fprop(xd, wd, g).cpu().permute(0, 3, 1, 2)
@@ -101,4 +102,10 @@ def test_site_parity_full_size(site, dev):
             es = (dwo[co, ci, rr, ss].double() - dw_smp).abs().max().item() / scale_dw
             assert es <= 2e-5, (mode, 'wgrad vs fp64 samples', es)
         finally:
+            K.set_conv_arith('bf16x3')
             K.FPROP_X3, K.DGRAD_X3, K.WGRAD_X3 = prev
+
+
+@pytest.mark.parametrize('site', SITES, ids=lambda s: 'x'.join(map(str, s)))
+def test_site_parity_full_size(site, dev):
+    check_site(site, N, dev)

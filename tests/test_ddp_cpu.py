@@ -85,6 +85,51 @@ def test_gloo_world2_allreduce_matches_full_batch(bucket_mb):
         assert torch.allclose(torch.from_numpy(got), p.grad, rtol=1e-5, atol=1e-6)
 
 
+def _unused_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bdvcil_amd as bd
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    a, b, c = nn.Linear(6, 6), nn.Linear(6, 6), nn.Linear(6, 6)
+    model = nn.ModuleList([a, b, c])
+    reducer = bd.GradAllReducer(model, bucket_cap_mb=25.0)
+    x = torch.ones(2, 6) * (rank + 1)
+    for step in range(2):
+        for p in model.parameters():
+            p.grad = None
+        out = a(x)
+        if rank == 0:
+            out = out + b(x)              # b: used on rank 0 only; c: used by nobody
+        out.sum().backward()
+        reducer.finish()
+    q.put((rank, None if b.weight.grad is None else b.weight.grad.clone().numpy(), c.weight.grad is None,
+           a.weight.grad.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unused_parameters_are_agreed_on_across_ranks():
+    """A parameter one rank did not use gets the other rank's sum on BOTH ranks (so the weights cannot diverge); a parameter no
+    rank used keeps ``.grad = None`` everywhere -- torch's DistributedDataParallel semantics (libs/cil/cil.py:704-709)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unused_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, c0_none, a0), (_, b1, c1_none, a1) = res
+    assert b0 is not None and b1 is not None and abs(b0 - b1).max() == 0 and abs(b0).max() > 0
+    assert c0_none and c1_none
+    assert abs(a0 - a1).max() == 0
+
+
 def test_tail_bucket_split():
     """The bucket that closes last (earliest layers) is split so that only a small tail is reduced after backward."""
     import bdvcil_amd as bd
@@ -126,6 +171,12 @@ def test_bench_self_launch_without_torchrun():
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['value'] == 3.0 and rec['steps'] == 3      # all-reduce over both ranks: 1 + 2
+    # the record proves itself: ranks / backend / buckets come from the communicator and the reducer, and the time the step spent
+    # blocked in GradAllReducer.finish() is in it (bench.py writes the same keys into the GPU record)
+    cfg = rec['config']
+    assert cfg['parallelism'] == 'dp2' and cfg['rccl']['ranks'] == 2 and cfg['rccl']['backend'] == 'gloo'
+    assert cfg['rccl']['buckets'] >= 2 and cfg['rccl']['payload_mb'] > 0 and len(cfg['rccl']['bucket_mb']) == cfg['rccl']['buckets']
+    assert cfg['allreduce_exposed_ms'] is not None and cfg['allreduce_exposed_ms'] >= 0
     # a launcher that starts the wrong number of ranks is refused
     env2 = dict(env, WORLD_SIZE='3', RANK='0', LOCAL_RANK='0')
     bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--selftest-cpu'], env=env2,

@@ -3,9 +3,10 @@ oracle/i3d_oracle.py (parity unpinned: mmaction2's ResNet3d is not vendored and 
 
 Bars: kernels 2e-5 of the output scale (fp32 both sides); model logits within 1e-3 with identical arg-max; training step: loss
 1e-4 relative, parameter gradients by relative L2 error against the fp64 oracle, no further from it than 3x the fp32 CPU oracle
-plus 3e-2 (ReLU / max-pool ties flip in any two fp32 implementations, see test_model_gpu.py; at this test's clip size the
-BatchNorm populations of layer3 / layer4 are 64 and 16 values per channel, so one flipped sign moves a channel's gradient by
-per cents -- observed 1.6e-2 on one layer3 tensor where the fp32 CPU oracle happened to have no flip)."""
+plus 1e-4 -- except upstream of a COUNTED flip (a ReLU sign, a pool1 arg-max or a pool2 winner that differs from the fp64 oracle's
+where fp32 rounding can reach it; read back and counted as in test_model_gpu.py), where the floor is 3e-2: at this test's clip
+size the BatchNorm populations of layer3 / layer4 are tens of values per channel, so one flipped sign moves a channel's gradient
+by per cents."""
 import copy
 
 import pytest
@@ -147,33 +148,143 @@ def test_i3d_eval_logits(T, S, clips, dev, conv_arith):
             assert torch.equal(o.argmax(1), r.argmax(1))
 
 
-def test_i3d_train_step(dev, conv_arith):
+class _ReluRecorder3d:
+    """Arguments of every F.relu call of the I3D oracle's backbone (5-D tensors), in execution order: stem, then per block conv1,
+    conv2, block output.  The oracle calls ``F.relu`` through its module-level ``F`` (oracle/i3d_oracle.py)."""
+
+    class _Proxy:
+        def __init__(self, real, sink):
+            self._real, self._sink = real, sink
+
+        def relu(self, x, *a, **kw):
+            if x.dim() == 5:
+                self._sink.append(x.detach())
+            return self._real.relu(x, *a, **kw)
+
+        def __getattr__(self, name):
+            return getattr(self._real, name)
+
+    def __enter__(self):
+        self.pre, self._saved = [], I.F
+        I.F = _ReluRecorder3d._Proxy(self._saved, self.pre)
+        return self
+
+    def __exit__(self, *exc):
+        I.F = self._saved
+        return False
+
+
+def _frames(t):
+    """(B, C, T, H, W) -> (B*T, C, H, W): the frame-major order of the HIP path's NHWC storage"""
+    B, C, T, H, W = t.shape
+    return t.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+
+
+def _i3d_site_owners(ref):
+    sites = [['backbone.conv1.']]
+    for li in range(1, 5):
+        for bi, _ in enumerate(getattr(ref.backbone, f'layer{li}')):
+            pre = f'backbone.layer{li}.{bi}.'
+            sites += [[pre + 'conv1.'], [pre + 'conv2.'], [pre + 'conv3.', pre + 'downsample.']]
+    return sites
+
+
+def _count_pool2_flips(pre64, pre32, sel):
+    """pool2 = MaxPool3d((2,1,1)): which frame of a pair wins is as discontinuous as a ReLU sign.  ``sel`` (bdv_maxpool_t2_fwd): one
+    bit per output element, set when the second frame won.  Differences from the fp64 oracle are legitimate only where the two
+    candidates are within max(1e-5, 3 x the fp32 CPU oracle's deviation) of the channel scale of each other; pairs whose maximum
+    is <= 0 are left aside (both candidates are zero after the ReLU: a tie, and the ReLU masks the gradient wherever it lands)."""
+    import numpy as np
+    act = pre64.clamp_min(0)                                     # (B, C, T, H, W): layer1's output
+    B, C, T, H, W = act.shape
+    a, b = act[:, :, 0::2], act[:, :, 1::2]
+    want = (b > a).permute(0, 2, 3, 4, 1).reshape(-1)           # (B, T/2, H, W, C) flat = the HIP output order
+    bits = torch.from_numpy(np.unpackbits(sel.cpu().numpy().view(np.uint8), bitorder='little').astype(bool))
+    live = (torch.maximum(a, b) > 0).permute(0, 2, 3, 4, 1).reshape(-1)
+    diff = (bits != want) & live
+    n = int(diff.sum())
+    if n:
+        cmax = pre64.abs().amax(dim=(0, 2, 3, 4), keepdim=True)
+        noise32 = float(((pre32.double() - pre64).abs() / cmax).max())
+        gap = ((a - b).abs() / cmax).permute(0, 2, 3, 4, 1).reshape(-1)[diff]
+        bar = max(1e-5, 3 * noise32)
+        assert float(gap.max()) <= bar, f'pool2: the winner differs where the candidates are {float(gap.max()):.2e} of the channel scale apart'
+    return n
+
+
+@pytest.mark.parametrize('T,S,B', [(8, 64, 2), (16, 96, 2)])
+def test_i3d_train_step(T, S, B, dev, conv_arith):
+    """Loss, accuracies, every parameter gradient and the BatchNorm statistics of one training step, judged as
+    tests/test_model_gpu.py::test_train_step judges the TSM path: the ReLU sign bits the HIP path wrote, pool1's arg-max codes and
+    pool2's winners are read back and compared with the fp64 oracle's; a difference must sit where fp32 rounding can reach it, and
+      * parameters with NO counted flip behind them (in backward order) are held to  relL2 <= 3 * e_f32 + 1e-4,
+      * parameters upstream of a counted flip keep the looser  3 * e_f32 + 3e-2  (at this clip size the BatchNorm populations of
+        layer3 / layer4 are tens of values per channel: one flipped sign moves a channel's gradient by per cents)."""
     import bdvcil_amd as bd
+    from bdvcil_amd import functional as Fn
+    from test_model_gpu import _report, count_pool_flips, count_relu_flips     # (tests/ is on sys.path: pytest rootdir import)
     K_ = 9
     ref, mod = _pair(K_, dev, seed=2)
     ref64 = copy.deepcopy(ref).double()
     gen = torch.Generator().manual_seed(7)
-    imgs = torch.randn(2, 1, 3, 8, 64, 64, generator=gen)
-    labels = torch.randint(0, K_, (2, 1), generator=gen)
+    imgs = torch.randn(B, 1, 3, T, S, S, generator=gen)
+    labels = torch.randint(0, K_, (B, 1), generator=gen)
     ref.train(); mod.train(); ref64.train()
-    rl = ref(imgs, labels)
+    with _ReluRecorder3d() as rec32:
+        rl = ref(imgs, labels)
     rl['loss_cls'].backward()
-    r64 = ref64(imgs.double(), labels)
+    with _ReluRecorder3d() as rec:
+        r64 = ref64(imgs.double(), labels)
     r64['loss_cls'].backward()
-    ol = mod(imgs.to(dev), labels.to(dev))
+    Fn.RELU_MASK_TAP = taps = []
+    Fn.POOL_IDX_TAP = pools = []
+    try:
+        ol = mod(imgs.to(dev), labels.to(dev))
+    finally:
+        Fn.RELU_MASK_TAP = Fn.POOL_IDX_TAP = None
     ol['loss_cls'].backward()
-    # layer4's BatchNorms normalise over 8 samples here (2 clips x 1 frame x 2x2): the fp32 CPU oracle itself is 3.5e-4 away
-    # from its fp64 run in the loss and 1.1e-4 (relative) in a running variance.  Every bar below is therefore stated against
-    # the fp64 oracle: 3x the fp32 CPU oracle's own distance from it, plus the plain tolerance.
+    # layer4's BatchNorms normalise over few samples here: the fp32 CPU oracle itself is 3.5e-4 away from its fp64 run in the loss
+    # and 1.1e-4 (relative) in a running variance.  Every bar below is therefore stated against the fp64 oracle: 3x the fp32 CPU
+    # oracle's own distance from it, plus the plain tolerance.
     l64 = r64['loss_cls'].item()
     assert abs(ol['loss_cls'].item() - l64) <= 3 * abs(rl['loss_cls'].item() - l64) + 1e-4 * max(1.0, abs(l64))
     assert abs(ol['top1_acc'].item() - rl['top1_acc'].item()) < 1e-6
+    pre64, pre32 = [_frames(p) for p in rec.pre], [_frames(p) for p in rec32.pre]
+    flips, flips32 = count_relu_flips(pre64, pre32, taps)
+    owners = _i3d_site_owners(ref)
+    assert len(owners) == len(flips) == 1 + 3 * 16
+    last_flip = max([k for k, n in enumerate(flips) if n], default=-1)
+    assert len(pools) == 2                                  # pool1's arg-max codes, pool2's winners
+    # pool1 = the spatial 3x3 / 2 max-pool of the even frames of the stem activation
+    Bc, C0, To, H0, W0 = rec.pre[0].shape
+    even = lambda t: t[:, :, 0::2].permute(0, 2, 1, 3, 4).reshape(-1, C0, H0, W0)      # noqa: E731
+    pool1_flips = count_pool_flips(even(rec.pre[0]), even(rec32.pre[0]), pools[0])
+    pool2_flips = _count_pool2_flips(rec.pre[9], rec32.pre[9], pools[1])                 # site 9 = layer1's output
+    if pool1_flips:
+        last_flip = max(last_flip, 0)
+    if pool2_flips:
+        last_flip = max(last_flip, 9)
+    _report(f'[relu flips] I3D T={T} S={S} B={B} {conv_arith}: {sum(flips)} of {sum(p.numel() for p in rec.pre)} signs differ from the '
+            f'fp64 oracle at sites {[k for k, n in enumerate(flips) if n]} (fp32 CPU oracle: {sum(flips32)} at '
+            f'{[k for k, n in enumerate(flips32) if n]}); pool1 arg-max differs at {pool1_flips}, pool2 winner at {pool2_flips} elements')
+
+    def behind_a_flip(name):
+        for k, prefixes in enumerate(owners):
+            if any(name.startswith(q) for q in prefixes):
+                return k <= last_flip
+        return False                                        # head: after every ReLU of the backbone
     rp, r64p, op = dict(ref.named_parameters()), dict(ref64.named_parameters()), dict(mod.named_parameters())
+    worst = {}
     for name, p in rp.items():
         assert op[name].grad is not None, name
         assert tuple(op[name].grad.shape) == tuple(p.shape), name
         e_hip, e_f32 = _rel_l2(op[name].grad, r64p[name].grad), _rel_l2(p.grad, r64p[name].grad)
-        assert e_hip <= 3 * e_f32 + 3e-2, (name, e_hip, e_f32)
+        loose = behind_a_flip(name)
+        assert e_hip <= 3 * e_f32 + (3e-2 if loose else 1e-4), (name, e_hip, e_f32, 'behind a counted flip' if loose else 'no flip behind it', flips)
+        if e_hip > worst.get(loose, (0,))[0]:
+            worst[loose] = (e_hip, e_f32, name)
+    _report(f'[grad parity] I3D T={T} S={S} B={B} {conv_arith}: worst (relL2 hip, relL2 fp32 CPU, name) with no flip behind: '
+            f'{worst.get(False)}; behind a flip: {worst.get(True)}')
     rb, r64b, ob = dict(ref.named_buffers()), dict(ref64.named_buffers()), dict(mod.named_buffers())
     for name, b in rb.items():
         if name.endswith('num_batches_tracked'):
