@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # is then the caller's business
 _OVERRIDE = os.environ.get('BDVCIL_LIB_PATH')
 LIB_PATH = _OVERRIDE or os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _lib = None
 
@@ -93,7 +93,8 @@ SIGNATURES = {
     'bdv_bn_relu_maxpool_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'bdv_avgpool_fwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_avgpool_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
-    'bdv_bgmix_normalize_u8': (c_int, [P, P, P, c_float, _F3, _F3, _F3, P, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_bgmix_normalize_u8': (c_int, [P, P, c_int, P, c_float, _F3, _F3, _F3, P, P, c_int, c_int, c_int, c_int, P]),
+    'bdv_bg_resize_crop_u8': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, P]),
     'bdv_crop_normalize_u8': (c_int, [P, P, c_int, c_int, c_int, _F3, _F3, P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_lsc_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_lsc_bwd': (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, P]),
@@ -102,7 +103,7 @@ SIGNATURES = {
     'bdv_consensus_fwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'bdv_consensus_bwd': (c_int, [P, P, c_int, c_int, c_int, P]),
     'bdv_dropout': (c_int, [P, P, c_int64, c_float, c_uint64, P]),
-    'bdv_lsc_loss': (c_int, [P, P, P, c_float, c_int, P, P, P, c_int, c_int, P]),
+    'bdv_lsc_loss': (c_int, [P, P, P, c_float, c_int, P, P, P, P, c_int, c_int, P]),
     'bdv_softce_loss': (c_int, [P, P, P, P, P, c_int, c_int, P]),
     'bdv_icarl_targets': (c_int, [P, P, c_int, P, P, c_int, c_int, P]),
     'bdv_acm_targets': (c_int, [P, P, P, c_float, P, c_int, c_int, P]),

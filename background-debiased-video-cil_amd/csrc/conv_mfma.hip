@@ -21,6 +21,28 @@
 #include <stdlib.h>
 #include "common.h"
 
+// ---- in-kernel time stamps (diagnostic builds only: make stamps -> libbdvcil_hip_stamps.so, tools/stamp_tiles.py) --------------
+// With -DBDV_STAMPS lane 0 of every workgroup of the plane kernels writes s_memtime at five points of its life (start, first
+// K-step published, K loop done, epilogue issued, stores drained) plus s_memrealtime at both ends and its hardware id into a
+// buffer of its own (bdv_debug_set_stamps); no output value depends on them.  Without the macro BDV_STAMP expands to nothing:
+// the product library executes no stamp.
+#ifdef BDV_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+__device__ int g_stamp_cap = 0;
+#define BDV_STAMP(slot)                                                                                                          \
+  do {                                                                                                                           \
+    if (threadIdx.x == 0 && g_stamp_buf != nullptr && (int)(blockIdx.x + gridDim.x * blockIdx.y) < g_stamp_cap) {                 \
+      unsigned long long* q_ = g_stamp_buf + (size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8;                                  \
+      if ((slot) == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+      q_[slot] = __builtin_amdgcn_s_memtime();                                                                                   \
+      if ((slot) == 0) { q_[5] = __builtin_amdgcn_s_memrealtime(); q_[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } \
+      if ((slot) == 4) q_[6] = __builtin_amdgcn_s_memrealtime();                                                                 \
+    }                                                                                                                            \
+  } while (0)
+#else
+#define BDV_STAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int BK = 32;
@@ -33,6 +55,7 @@ struct Geom {
   int M;     // GEMM rows: N*Ho*Wo (fprop / wgrad reduction length), N*H*W (dgrad)
   int Ktot;  // fprop: R*S*Cin ; dgrad: R*S*Cout ; wgrad: row length of dw = R*S*Cin
   float rcp_HoWo, rcp_Wo;  // fast division helpers (dividends < 2^22)
+  int stagger;             // two-stage plane kernels: SIMD partners run a K-step in opposite order (pl_pipeline2)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -1982,23 +2005,45 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 // one register set and `if (kt + 1 < ke)` around every store).  n = number of K-steps; load(set) loads the NEXT step in order.
 using PlSet0 = std::integral_constant<int, 0>;
 using PlSet1 = std::integral_constant<int, 1>;
+// STAGGER (round 3): the two waves of a SIMD run the steady-state step in OPPOSITE order.  A step's MFMAs (48 - 96 per wave) and its
+// vector work (the piece split of the next activation tile, the LDS stores, the loads' address arithmetic: ~170 instructions) were
+// one after the other in every wave, and the barrier kept SIMD partners in the same phase -- the matrix pipe idled while both waves
+// split, the vector issue idled while both multiplied: in-kernel stamps (tools/stamp_tiles.py) give 2.24 us per K-step of the
+// 128x256 tile = 4370 cycles at 1.95 GHz for 3072 cycles of MFMA work, the rest being the ~1360 cycles the two waves' vector work
+// takes to issue.  Waves >= NW/2 (the SIMD partners of waves 0 .. NW/2 - 1: a workgroup's waves go to the SIMDs in cyclic order) now
+// do store + load first and the MFMAs last, so one wave's vector block runs beside its partner's MFMA block.  Any order inside a
+// step is legal: the stage a step stores was read before the previous barrier, the stage it reads was stored before it.
 template <typename LoadF, typename StoreF, typename MmaF>
-__device__ __forceinline__ void pl_pipeline2(int n, LoadF&& load, StoreF&& store, MmaF&& mma) {
+__device__ __forceinline__ void pl_pipeline2(int n, LoadF&& load, StoreF&& store, MmaF&& mma, bool late = false) {
   load(PlSet0{});
   store(0, PlSet0{});
   if (n > 1) load(PlSet1{});
   if (n > 2) load(PlSet0{});
   __syncthreads();
+  BDV_STAMP(1);
   int i = 0;
-  for (; i + 4 < n; i += 2) {
-    mma(0);
-    store(1, PlSet1{});
-    load(PlSet1{});
-    __syncthreads();
-    mma(1);
-    store(0, PlSet0{});
-    load(PlSet0{});
-    __syncthreads();
+  if (late) {
+    for (; i + 4 < n; i += 2) {
+      store(1, PlSet1{});
+      load(PlSet1{});
+      mma(0);
+      __syncthreads();
+      store(0, PlSet0{});
+      load(PlSet0{});
+      mma(1);
+      __syncthreads();
+    }
+  } else {
+    for (; i + 4 < n; i += 2) {
+      mma(0);
+      store(1, PlSet1{});
+      load(PlSet1{});
+      __syncthreads();
+      mma(1);
+      store(0, PlSet0{});
+      load(PlSet0{});
+      __syncthreads();
+    }
   }
   for (; i < n; i += 2) {
     mma(0);
@@ -2021,7 +2066,9 @@ __device__ __forceinline__ void pl_pipeline2(int n, LoadF&& load, StoreF&& store
 // the tile fits 128 VGPRs: measured per training step at batch 64 (gpurun_out/np1_*.log), fprop 128x256 7.40 -> 6.39 ms (52 - 64
 // bytes of scratch), fprop 256x64 1.97 -> 1.39, dgrad 256x64 3.64 -> 3.19; the others spill their accumulators (236 - 600 bytes
 // per lane) and run 2 - 3 x slower (dgrad 128x256 13.3 -> 25.3 ms), so they keep one workgroup per CU.
-constexpr int pl_waves_per_simd(int waves, int np, bool fits128) { return np == 1 && waves == 8 && fits128 ? 4 : waves / 4; }
+// Four-wave workgroups (the 128x128 tile, round 3): two per CU (256 VGPRs each), so that one tile's prologue / epilogue runs beside
+// the other's K loop.
+constexpr int pl_waves_per_simd(int waves, int np, bool fits128) { return np == 1 && waves == 8 && fits128 ? 4 : waves == 4 ? 2 : waves / 4; }
 
 // ---- fprop ------------------------------------------------------------------------------------
 // ES: bytes per element of x / y / the residual (4 = fp32, 2 = bf16 storage: NP = 1 only, the loader's conversion is then exact)
@@ -2043,6 +2090,7 @@ __global__ __launch_bounds__(64 * WM * WN, pl_waves_per_simd(WM * WN, NP, BN == 
   __shared__ __attribute__((aligned(16))) unsigned char smem_b[SMEM];
   float* const smem = reinterpret_cast<float*>(smem_b);
 
+  BDV_STAMP(0);
   const int nk = g.Ktot / BK;
   const WorkItem it = get_work(blockIdx.x, wk, nk);
   const int mt = it.tile / NT, nt = it.tile - mt * NT;
@@ -2159,23 +2207,27 @@ __global__ __launch_bounds__(64 * WM * WN, pl_waves_per_simd(WM * WN, NP, BN == 
   if constexpr (NBUF == 2) {
     pl_pipeline2(it.ke - it.kb, load, store, [&](int stage) __attribute__((always_inline)) {
       mma_stage_pl<BM, BN, WM, WN, NP>(smem_b + stage * STAGE, smem_b + stage * STAGE + NP * PA, acc, fa, fb);
-    });
+    }, g.stagger != 0 && wave >= WM * WN / 2);
   } else {
     load(PlSet0{});
     for (int kt = it.kb; kt < it.ke; ++kt) {
       __syncthreads();
       store(0, PlSet0{});
       __syncthreads();
+      if (kt == it.kb) BDV_STAMP(1);
       if (kt + 1 < it.ke) load(PlSet0{});
       mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + NP * PA, acc, fa, fb);
     }
   }
+  BDV_STAMP(2);
 
   if (it.pslot >= 0) {
     store_partial<TM, TN, NTHR>(slab, it.pslot, acc, tid);
     return;
   }
   fprop_epilogue<BM, BN, WM, WN, ES>(acc, smem, y, g, epi, mt, nt, tid);
+  BDV_STAMP(3);
+  BDV_STAMP(4);
 }
 
 // ---- dgrad ------------------------------------------------------------------------------------
@@ -2199,6 +2251,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM *
   __shared__ __attribute__((aligned(16))) unsigned char smem_b[SMEM];
   float* const smem = reinterpret_cast<float*>(smem_b);
 
+  BDV_STAMP(0);
   // parity class of the input pixel (stride 1: a single class)
   const int st = g.stride;
   const int ph = blockIdx.y / st, pw = blockIdx.y - ph * st;
@@ -2321,18 +2374,20 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM *
     if constexpr (NBUF == 2) {
       pl_pipeline2(it.ke - it.kb, load, store, [&](int stage) __attribute__((always_inline)) {
         mma_stage_pl<BM, BN, WM, WN, NP>(smem_b + stage * STAGE, smem_b + stage * STAGE + NP * PA, acc, fa, fb);
-      });
+      }, g.stagger != 0 && wave >= WM * WN / 2);
     } else {
       load(PlSet0{});
       for (int kt = it.kb; kt < it.ke; ++kt) {
         __syncthreads();
         store(0, PlSet0{});
         __syncthreads();
+        if (kt == it.kb) BDV_STAMP(1);
         if (kt + 1 < it.ke) load(PlSet0{});
         mma_stage_pl<BM, BN, WM, WN, NP>(smem_b, smem_b + NP * PA, acc, fa, fb);
       }
     }
   }
+  BDV_STAMP(2);
   if (it.pslot >= 0) {
     store_partial<TM, TN, NTHR>(slab, it.pslot, acc, tid);
     return;
@@ -2344,6 +2399,8 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM *
     const int hc = rem / Wc;
     return (n * g.H + hc * st + ph) * g.W + (rem - hc * Wc) * st + pw;
   });
+  BDV_STAMP(3);
+  BDV_STAMP(4);
 }
 
 // ---- wgrad, "P" family ---------------------------------------------------------------------------
@@ -2603,7 +2660,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const vo
   };
   if (kt_begin < kt_end) {
     if constexpr (NST == 2) {
-      pl_pipeline2(kt_end - kt_begin, load, store, mma);
+      pl_pipeline2(kt_end - kt_begin, load, store, mma, g.stagger != 0 && (int)(threadIdx.x >> 6) >= WM * WN / 2);
     } else {
       load(PlSet0{});
       for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -2664,8 +2721,15 @@ int check_geom(const bdv_conv_geom* g, const char* who) {
   return BDV_OK;
 }
 
+// BDVCIL_STAGGER=0 turns the wave stagger of pl_pipeline2 off (A/B runs); read per call, so that tools can flip it between rounds
+static bool pl_stagger_enabled() {
+  const char* e = getenv("BDVCIL_STAGGER");
+  return e == nullptr || atoi(e) != 0;
+}
+
 Geom make_geom(const bdv_conv_geom* g) {
   Geom d;
+  d.stagger = pl_stagger_enabled() ? 1 : 0;
   d.N = g->N; d.H = g->H; d.W = g->W; d.Cin = g->Cin; d.Ho = g->Ho; d.Wo = g->Wo; d.Cout = g->Cout;
   d.R = g->R; d.S = g->S; d.stride = g->stride; d.pad = g->pad; d.pad_w = g->pad_w < 0 ? g->pad : g->pad_w;
   d.T = (g->fold > 0 || g->Rt > 1) ? g->T : 1;
@@ -2785,10 +2849,16 @@ struct PlCfg {
   int BM, BN, nbuf;
   double iter_us;  // one 32-deep K-step of a block, measured per-CU rate (tools/ubench/gemm_x3p.hip: ~200 / ~230 TFLOP/s chip-wide)
 };
-constexpr int kNumPlCfg = 5;
+constexpr int kNumPlCfg = 6;
 // 4 = 64 x 128, four waves, FOUR workgroups per CU: for dgrads whose epilogue streams as many bytes as their K loop takes MFMA time
 // (a block's conv1), so that one tile's epilogue runs beside other tiles' K loops; dgrad only
-constexpr PlCfg kPlCfg[kNumPlCfg] = {{128, 256, 2, 2.7}, {256, 128, 2, 2.7}, {256, 256, 1, 4.7}, {256, 64, 2, 1.9}, {64, 128, 1, 0.7}};
+// 5 = 128 x 128, four waves, TWO workgroups per CU, one LDS stage (48 KB): the tile of the round-1 conv_*_x3 kernels on the plane
+// kernels' conflict-free LDS image (64-byte rows, 16-byte chunk XOR, immediate-offset fragment reads) and their weight planes
+constexpr PlCfg kPlCfg[kNumPlCfg] = {{128, 256, 2, 2.7}, {256, 128, 2, 2.7}, {256, 256, 1, 4.7}, {256, 64, 2, 1.9}, {64, 128, 1, 0.7},
+                                     {128, 128, 1, 1.6}};
+constexpr int pl_cfg_wm(int cfg) { return cfg == 0 || cfg == 2 || cfg == 4 || cfg == 5 ? 2 : 4; }
+constexpr int pl_cfg_wn(int cfg) { return cfg == 4 || cfg == 5 ? 2 : 8 / pl_cfg_wm(cfg); }
+constexpr int pl_cfg_round(int cfg) { return cfg == 5 ? 512 : 256; }   // workgroups resident on the chip at once
 
 struct PlPlan {
   int cfg;  // -1: shape not covered by the P kernels
@@ -2799,8 +2869,7 @@ struct PlPlan {
 };
 
 // DP whole rounds of 256 blocks, the remainder tiles K-split `s` ways (fix-up kernel): cost in us incl. the fix-up's slab traffic
-Work plan_work_pl(int tiles, int nk, double iter_us, size_t seg_bytes, size_t ws_bytes, double* est_us) {
-  const int W = 256;
+Work plan_work_pl(int tiles, int nk, double iter_us, size_t seg_bytes, size_t ws_bytes, double* est_us, int W = 256) {
   Work wk;
   const int q = tiles / W, r = tiles - q * W;
   wk.dp_tiles = tiles;
@@ -2877,11 +2946,9 @@ int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride, int pieces = 3,
     if (nk >= 16 || nk <= 2) return 0;
     return -1;
   }
-  static const int small_mode = getenv("BDVCIL_DGRAD_64X128") != nullptr ? atoi(getenv("BDVCIL_DGRAD_64X128")) : 0;
-  const bool small_tiles = small_mode == 1;
-  // 2: only the conv1 dgrads of layer 1 / 2 (K <= 128: the sites furthest above their HBM time), 3: layer 1 only -- three alternating
-  // runs each: 591.0 (off), 591.3 (2), 592.6 (3) clips/s on average, i.e. level within the run-to-run spread: tuning switches only
-  if ((small_mode == 2 && shifted && taps == 1 && nk <= 4) || (small_mode == 3 && shifted && taps == 1 && nk <= 2)) return ncols % 128 == 0 ? 4 : -1;
+  // (round 2 also had modes 2 / 3 -- the conv1 dgrads of layers 1-2 / layer 1 only: level within the run-to-run spread,
+  // profiles/r02_ab_streams.txt; removed)
+  static const bool small_tiles = getenv("BDVCIL_DGRAD_64X128") != nullptr && atoi(getenv("BDVCIL_DGRAD_64X128")) == 1;
   if (ncols % 256 != 0) return taps > 1 && stride == 1 ? 1 : (small_tiles && taps == 1 && stride == 1 && nk >= 16 ? 4 : -1);
   if (stride == 2 && taps > 1) return 0;
   if (small_tiles && shifted && taps == 1) return 4;
@@ -2904,7 +2971,7 @@ PlPlan plan_pl(int cfg, int M, int ncols, int nk, size_t ws_bytes, bool ksplit_o
   p.nk = nk;
   p.seg_bytes = (size_t)k.BM * k.BN * sizeof(float);
   if (ksplit_ok && cfg != 4) {   // (the 64 x 128 tile runs four workgroups per CU: thousands of tiles, no remainder worth splitting)
-    p.wk = plan_work_pl(p.MT * p.NT, nk, k.iter_us, p.seg_bytes, ws_bytes, &p.est_us);
+    p.wk = plan_work_pl(p.MT * p.NT, nk, k.iter_us, p.seg_bytes, ws_bytes, &p.est_us, pl_cfg_round(cfg));
   } else {
     p.wk.dp_tiles = p.MT * p.NT;
     p.wk.rem_tiles = 0;
@@ -2914,12 +2981,9 @@ PlPlan plan_pl(int cfg, int M, int ncols, int nk, size_t ws_bytes, bool ksplit_o
   return p;
 }
 
-// the two-workgroups-per-CU bf16-piece kernels read their weight operand from the planes as well (BDVCIL_R1_PLANES=0: split it
-// in the K loop, as in round 1)
-bool r1_planes_enabled() {
-  static const bool on = getenv("BDVCIL_R1_PLANES") == nullptr || atoi(getenv("BDVCIL_R1_PLANES")) != 0;
-  return on;
-}
+// the two-workgroups-per-CU bf16-piece kernels read their weight operand from the planes as well (round 2's BDVCIL_R1_PLANES=0,
+// "split it in the K loop as in round 1", is gone: 14.56 -> 13.98 ms over all fprop sites was its A/B)
+constexpr bool r1_planes_enabled() { return true; }
 
 // the stem (Cin = 4) on the bf16-piece K loop (BDVCIL_C4_X3=0: on the fp32-MFMA kernel, as in round 1)
 bool c4_x3_enabled() {
@@ -3269,8 +3333,18 @@ extern "C" size_t bdv_conv_weight_planes_bytes(const bdv_conv_geom* gg) {
   return (size_t)3 * gg->Cout * gg->R * gg->S * gg->Cin * sizeof(unsigned short);
 }
 
+#ifdef BDV_STAMPS
+// diagnostic builds only (not declared in include/bdvcil_hip.h, not in the product library): where the kernels write their stamps
+extern "C" int bdv_debug_set_stamps(void* buf, int cap_workgroups) {
+  unsigned long long* p = (unsigned long long*)buf;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_cap), &cap_workgroups, sizeof(int)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
+
 extern "C" int bdv_conv_debug_force_tile(int cfg) {
-  BDV_REQUIRE(cfg >= -1 && cfg <= kNumPlCfg, "bdv_conv_debug_force_tile: cfg %d (-1 automatic, 0 = 128x256, 1 = 256x128, 2 = 256x256, 3 = 256x64, 4 = 64x128 (dgrad), 5 = none)", cfg);
+  BDV_REQUIRE(cfg >= -1 && cfg <= kNumPlCfg, "bdv_conv_debug_force_tile: cfg %d (-1 automatic, 0 = 128x256, 1 = 256x128, 2 = 256x256, 3 = 256x64, 4 = 64x128 (dgrad), 5 = 128x128 (four waves), 6 = none)", cfg);
   g_pl_tile_forced = cfg;
   return BDV_OK;
 }
@@ -3285,8 +3359,7 @@ extern "C" int bdv_conv_kernel_name(const bdv_conv_geom* gg, int kind, int arith
   if (kind == 0) {
     const int cfg = arith ? pl_fprop_cfg(gg, arith == 2 ? 1 : 3) : -1;
     if (cfg >= 0) {
-      const int wm = cfg == 0 || cfg == 2 ? 2 : 4;
-      snprintf(out, n, "conv_fprop_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, wm, 8 / wm, kPlCfg[cfg].nbuf, arith == 2 ? 1 : 3);
+      snprintf(out, n, "conv_fprop_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, pl_cfg_wm(cfg), pl_cfg_wn(cfg), kPlCfg[cfg].nbuf, arith == 2 ? 1 : 3);
     } else if (c4) {
       snprintf(out, n, "conv_fprop_c4_%skernel<128, %d, 2, 2>", arith && c4_x3_enabled() ? "x3_" : "", gg->Cout % 128 == 0 ? 128 : 64);
     } else if (gg->Cout % 128 == 0 && arith) {
@@ -3297,8 +3370,7 @@ extern "C" int bdv_conv_kernel_name(const bdv_conv_geom* gg, int kind, int arith
   } else if (kind == 1) {
     const int cfg = arith ? pl_dgrad_cfg(gg, arith == 2 ? 1 : 3) : -1;
     if (cfg >= 0) {
-      const int wm = cfg == 0 || cfg == 2 || cfg == 4 ? 2 : 4;
-      snprintf(out, n, "conv_dgrad_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, wm, cfg == 4 ? 2 : 8 / wm, kPlCfg[cfg].nbuf, arith == 2 ? 1 : 3);
+      snprintf(out, n, "conv_dgrad_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, pl_cfg_wm(cfg), pl_cfg_wn(cfg), kPlCfg[cfg].nbuf, arith == 2 ? 1 : 3);
     } else if (gg->Cin % 128 == 0 && arith) {
       snprintf(out, n, "conv_dgrad_x3_kernel<128, 128, 2, 2, %s>", r1_planes_enabled() ? "true" : "false");
     } else {
@@ -3437,6 +3509,7 @@ extern "C" int bdv_conv_fprop_pl(const void* x, const float* w, const void* plan
   if (p.cfg == 0) BDV_FPROP_PL(128, 256, 2, 4, 2);
   else if (p.cfg == 1) BDV_FPROP_PL(256, 128, 4, 2, 2);
   else if (p.cfg == 2) BDV_FPROP_PL(256, 256, 2, 4, 1);
+  else if (p.cfg == 5) BDV_FPROP_PL(128, 128, 2, 2, 1);
   else BDV_FPROP_PL(256, 64, 4, 2, 2);
 #undef BDV_FPROP_PL
   return BDV_OK;
@@ -3519,6 +3592,7 @@ extern "C" int bdv_conv_dgrad_pl(const void* dy, const float* w, const void* pla
   else if (p.cfg == 1) BDV_DGRAD_PL(256, 128, 4, 2, 2);
   else if (p.cfg == 2) BDV_DGRAD_PL(256, 256, 2, 4, 1);
   else if (p.cfg == 4) BDV_DGRAD_PL(64, 128, 2, 2, 1);
+  else if (p.cfg == 5) BDV_DGRAD_PL(128, 128, 2, 2, 1);
   else BDV_DGRAD_PL(256, 64, 4, 2, 2);
 #undef BDV_DGRAD_PL
   return BDV_OK;

@@ -277,8 +277,11 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 // ---------------------------------------------------------------------------------------
 // LSCLoss (lsc_loss.py:36-56): one block, waves stride over rows, fixed-order final reduce.
 // ---------------------------------------------------------------------------------------
+// class_weights (lsc_loss.py:50-51, optional): the row's term num - log(den) is scaled by class_weights[target] BEFORE the negation
+// and the hinge, i.e. l_i = max(w_i * (log den - num), 0); a weight of 1 leaves every value bit for bit as without weights.
 __global__ __launch_bounds__(256) void lsc_loss_kernel(const float* __restrict__ sim, const int64_t* __restrict__ targets,
                                                         const float* __restrict__ eta_p, float margin, int hinge,
+                                                        const float* __restrict__ class_weights,
                                                         float* __restrict__ loss, float* __restrict__ dsim, float* __restrict__ deta,
                                                         int B, int K) {
   __shared__ float red[2][4];
@@ -307,7 +310,8 @@ __global__ __launch_bounds__(256) void lsc_loss_kernel(const float* __restrict__
     esum = wave_sum(esum);
     const float den = 1.f + esum;  // exp(0) of the zeroed positive slot (Appendix C.1)
     const float num = eta * (row[y] - margin) - mx;
-    const float l = logf(den) - num;
+    const float wgt = class_weights != nullptr ? class_weights[y] : 1.f;
+    const float l = wgt * (logf(den) - num);
     const bool active = !hinge || l >= 0.f;
     if (lane == 0) loss_acc += active ? l : 0.f;
     float dpart = 0.f;
@@ -316,6 +320,7 @@ __global__ __launch_bounds__(256) void lsc_loss_kernel(const float* __restrict__
       if (active) {
         g = (k == y) ? -1.f : expf(eta * (row[k] - margin) - mx) / den;
         if (k == am) g += 1.f / den;  // gradient through the row-max subtraction
+        g *= wgt;
       }
       dsim[(size_t)b * K + k] = g * eta * invB;
       dpart += g * (row[k] - margin);
@@ -581,10 +586,11 @@ extern "C" int bdv_dropout(const float* x, float* out, int64_t numel, float p, u
   return BDV_OK;
 }
 
-extern "C" int bdv_lsc_loss(const float* sim, const int64_t* targets, const float* eta, float margin, int hinge, float* loss,
+extern "C" int bdv_lsc_loss(const float* sim, const int64_t* targets, const float* eta, float margin, int hinge,
+                            const float* class_weights, float* loss,
                             float* dsim, float* deta, int B, int K, void* stream) {
   BDV_REQUIRE(sim && targets && eta && loss && dsim && deta && B > 0 && K > 0, "bdv_lsc_loss: bad argument");
-  hipLaunchKernelGGL(lsc_loss_kernel, dim3(1), dim3(256), 0, HL_STREAM, sim, targets, eta, margin, hinge, loss, dsim, deta, B, K);
+  hipLaunchKernelGGL(lsc_loss_kernel, dim3(1), dim3(256), 0, HL_STREAM, sim, targets, eta, margin, hinge, class_weights, loss, dsim, deta, B, K);
   BDV_LAUNCH_CHECK("bdv_lsc_loss");
   return BDV_OK;
 }

@@ -174,7 +174,10 @@ struct NormParams {
 
 // Fused front-end.  One thread = one pixel of one clip position (b, h, w): the background pixel is
 // loaded and normalised once and reused for the T frames of the clip.
-__global__ __launch_bounds__(256) void bgmix_normalize_kernel(const uint8_t* __restrict__ frames, const uint8_t* __restrict__ bg,
+// BGF: the background arrives as fp32 pixel values in [0, 255] (the output of bg_resize_crop_kernel: torchvision's Resize on a
+// float image is not rounded back to uint8) instead of uint8.
+template <bool BGF>
+__global__ __launch_bounds__(256) void bgmix_normalize_kernel(const uint8_t* __restrict__ frames, const void* __restrict__ bg,
                                                                const uint8_t* __restrict__ mix, NormParams np,
                                                                float4* __restrict__ out_nhwc4, float* __restrict__ out_nchw,
                                                                int B, int T, int HW) {
@@ -189,9 +192,12 @@ __global__ __launch_bounds__(256) void bgmix_normalize_kernel(const uint8_t* __r
     const bool do_mix = mix != nullptr && mix[b] != 0;
     float bgn[3] = {0.f, 0.f, 0.f};
     if (do_mix) {
-      const uint8_t* q = bg + ((int64_t)b * HW + p) * 3;
+      const int64_t o = ((int64_t)b * HW + p) * 3;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) bgn[c] = ((float)q[c] - np.mean[c]) / np.std[c];
+      for (int c = 0; c < 3; ++c) {
+        const float v = BGF ? reinterpret_cast<const float*>(bg)[o + c] : (float)reinterpret_cast<const uint8_t*>(bg)[o + c];
+        bgn[c] = (v - np.mean[c]) / np.std[c];
+      }
     }
     const float one_m_alpha = 1.f - np.alpha;
     for (int t = 0; t < T; ++t) {
@@ -329,6 +335,57 @@ extern "C" int bdv_maxpool_t2_bwd(const float* dout, const uint32_t* sel, float*
   return BDV_OK;
 }
 
+
+namespace {
+// Background pipeline of BackgroundMixDataset before Normalize (libs/loader/comix_loader.py:72-73): torchvision Resize(size) of
+// the FLOAT image read by read_image(...).float() -- bilinear, align_corners=False, no antialias filter (identical to the
+// antialiased form whenever the image is enlarged, which is the case for every dataset of the configs: 240- and 256-pixel frames
+// to 256) -- followed by RandomCrop at (top[b], left[b]).  One thread = one output pixel; the arithmetic follows ATen's
+// upsample_bilinear2d (source index scale * (dst + 0.5) - 0.5 clamped at 0, lambda in fp32, rows combined after columns).
+__global__ __launch_bounds__(256) void bg_resize_crop_kernel(const uint8_t* __restrict__ src, const int32_t* __restrict__ top,
+                                                              const int32_t* __restrict__ left, float* __restrict__ out, int B, int Hs,
+                                                              int Ws, int Hr, int Wr, int ch, int cw) {
+#pragma clang fp contract(off)
+  const int64_t total = (int64_t)B * ch * cw;
+  const float sh = (float)Hs / (float)Hr, sw = (float)Ws / (float)Wr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / ((int64_t)ch * cw));
+    const int r = (int)(i - (int64_t)b * ch * cw);
+    const int y = r / cw + top[b], x = r % cw + left[b];
+    float fy = sh * ((float)y + 0.5f) - 0.5f, fx = sw * ((float)x + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    float ly = fy - (float)y0, lx = fx - (float)x0;
+    ly = fminf(fmaxf(ly, 0.f), 1.f);
+    lx = fminf(fmaxf(lx, 0.f), 1.f);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const uint8_t* img = src + (int64_t)b * Hs * Ws * 3;
+    const uint8_t *p00 = img + ((int64_t)y0 * Ws + x0) * 3, *p01 = img + ((int64_t)y0 * Ws + x1) * 3;
+    const uint8_t *p10 = img + ((int64_t)y1 * Ws + x0) * 3, *p11 = img + ((int64_t)y1 * Ws + x1) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float t0 = (float)p00[c] * hx + (float)p01[c] * lx;
+      const float t1 = (float)p10[c] * hx + (float)p11[c] * lx;
+      out[i * 3 + c] = t0 * hy + t1 * ly;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int bdv_bg_resize_crop_u8(const uint8_t* src, int B, int Hs, int Ws, int Hr, int Wr, const int32_t* top,
+                                     const int32_t* left, int crop_h, int crop_w, float* out, void* stream) {
+  BDV_REQUIRE(src && top && left && out, "bdv_bg_resize_crop_u8: null pointer");
+  BDV_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Hr > 0 && Wr > 0 && crop_h > 0 && crop_w > 0 && crop_h <= Hr && crop_w <= Wr,
+              "bdv_bg_resize_crop_u8: bad shape (%dx%d -> %dx%d, crop %dx%d)", Hs, Ws, Hr, Wr, crop_h, crop_w);
+  const int64_t total = (int64_t)B * crop_h * crop_w;
+  hipLaunchKernelGGL(bg_resize_crop_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, top, left, out, B, Hs, Ws,
+                     Hr, Wr, crop_h, crop_w);
+  BDV_LAUNCH_CHECK("bdv_bg_resize_crop_u8");
+  return BDV_OK;
+}
+
 extern "C" int bdv_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream) {
   BDV_REQUIRE(x && out && N > 0 && H > 0 && W > 0, "bdv_nchw3_to_nhwc4: bad argument");
   BDV_REQUIRE(bdv_aligned16(out), "bdv_nchw3_to_nhwc4: alignment");
@@ -435,7 +492,7 @@ extern "C" int bdv_crop_normalize_u8(const uint8_t* frames, const int32_t* crops
   return BDV_OK;
 }
 
-extern "C" int bdv_bgmix_normalize_u8(const uint8_t* frames, const uint8_t* bg, const uint8_t* mix, float alpha,
+extern "C" int bdv_bgmix_normalize_u8(const uint8_t* frames, const void* bg, int bg_f32, const uint8_t* mix, float alpha,
                                       const float mean[3], const float std[3], const float inv_std[3], float* out_nhwc4,
                                       float* out_nchw, int B, int T, int H, int W, void* stream) {
   BDV_REQUIRE(frames && mean && std && inv_std, "bdv_bgmix_normalize_u8: null pointer");
@@ -451,8 +508,12 @@ extern "C" int bdv_bgmix_normalize_u8(const uint8_t* frames, const uint8_t* bg, 
   }
   np.alpha = alpha;
   const int64_t total = (int64_t)B * H * W;
-  hipLaunchKernelGGL(bgmix_normalize_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, frames, bg, mix, np,
-                     (float4*)out_nhwc4, out_nchw, B, T, H * W);
+  if (bg_f32)
+    hipLaunchKernelGGL((bgmix_normalize_kernel<true>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, frames, bg, mix, np,
+                       (float4*)out_nhwc4, out_nchw, B, T, H * W);
+  else
+    hipLaunchKernelGGL((bgmix_normalize_kernel<false>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, frames, bg, mix, np,
+                       (float4*)out_nhwc4, out_nchw, B, T, H * W);
   BDV_LAUNCH_CHECK("bdv_bgmix_normalize_u8");
   return BDV_OK;
 }

@@ -4,7 +4,8 @@ Arithmetic of libs/loader/comix_loader.py:72-75 (bg: Normalize(bg_mean, bg_std))
 tensors) and UPSTREAM Normalize with ``img_norm_cfg`` (configs/.../bgmix_seed_1000_...:121-122), for a whole batch in
 one HBM pass: uint8 frames + uint8 background in, NHWC4 fp32 out (the stem's input layout).  The mix decision
 (``not randAug`` or ``random() < prob``, comix_loader.py:110-116) stays with the caller and arrives as ``mix``.
-File discovery / decoding / resize / crop are out of scope.
+The background's ``Resize -> RandomCrop`` (comix_loader.py:72-73) is ``BackgroundCropFrontEnd``; file discovery and JPEG decoding
+are out of scope.
 """
 from __future__ import annotations
 
@@ -22,7 +23,8 @@ class BackgroundMixFrontEnd:
         self.alpha, self.mean, self.std = float(alpha), tuple(mean), tuple(std)
 
     def __call__(self, frames_u8: torch.Tensor, bg_u8: torch.Tensor = None, mix: torch.Tensor = None) -> Nhwc4Frames:
-        """frames_u8 (B,T,H,W,3), bg_u8 (B,H,W,3), mix (B,) bool -> Nhwc4Frames (B*T,H,W,4)."""
+        """frames_u8 (B,T,H,W,3), bg_u8 (B,H,W,3) uint8 (or the fp32 output of ``BackgroundCropFrontEnd``), mix (B,) bool -> Nhwc4Frames
+        (B*T,H,W,4)."""
         o4, _ = K.bgmix_normalize_u8(frames_u8, bg_u8, mix, self.alpha, self.mean, self.std, True, False)
         return Nhwc4Frames(o4, frames_u8.shape[0], frames_u8.shape[1])
 
@@ -30,6 +32,44 @@ class BackgroundMixFrontEnd:
         """Same arithmetic, output shaped like the reference's collated batch: (B,T,3,H,W) fp32."""
         _, oc = K.bgmix_normalize_u8(frames_u8, bg_u8, mix, self.alpha, self.mean, self.std, False, True)
         return oc
+
+
+class BackgroundCropFrontEnd:
+    """``Resize(bg_resize)`` -> ``RandomCrop(bg_crop_size)`` of ``BackgroundMixDataset.bg_pipeline`` (libs/loader/comix_loader.py:72-73;
+    the constructor defaults ``bg_resize=256``, ``bg_crop_size=(224, 224)`` of :27-28) for a batch of uint8 background images of one size, in one kernel; its fp32 output
+    goes straight into ``BackgroundMixFrontEnd`` (which applies the pipeline's ``Normalize`` and the blend).  The crop offsets are
+    drawn as torchvision's ``RandomCrop.get_params`` draws them -- per image ``torch.randint(0, h - th + 1, (1,))`` then
+    ``torch.randint(0, w - tw + 1, (1,))`` on torch's global CPU generator, and no draw at all when the resized image already has
+    the crop's size -- so a seeded run picks the reference's crops.  Parity unpinned: torchvision is not importable here (its
+    version is not pinned by the reference either); the resampling follows ATen's bilinear kernel, which torchvision calls."""
+
+    def __init__(self, resize: int = 256, crop_size=(224, 224)):
+        self.resize = int(resize)
+        self.crop = (int(crop_size), int(crop_size)) if isinstance(crop_size, int) else (int(crop_size[0]), int(crop_size[1]))   # (h, w)
+
+    def draw(self, batch: int, h: int, w: int):
+        th, tw = self.crop
+        if h < th or w < tw:
+            raise ValueError(f'Required crop size {(th, tw)} is larger than input image size {(h, w)}')
+        tops, lefts = [], []
+        for _ in range(batch):
+            if (h, w) == (th, tw):
+                i = j = 0
+            else:
+                i = int(torch.randint(0, h - th + 1, size=(1,)).item())
+                j = int(torch.randint(0, w - tw + 1, size=(1,)).item())
+            tops.append(i)
+            lefts.append(j)
+        return tops, lefts
+
+    def __call__(self, bg_u8: torch.Tensor, offsets=None) -> torch.Tensor:
+        """bg_u8 (B,Hs,Ws,3) uint8 -> (B,crop,crop,3) fp32 pixel values.  ``offsets = (tops, lefts)`` overrides the draws."""
+        B, Hs, Ws, _ = bg_u8.shape
+        Hr, Wr = K.resized_size(Hs, Ws, self.resize)
+        tops, lefts = self.draw(B, Hr, Wr) if offsets is None else offsets
+        dev = bg_u8.device
+        return K.bg_resize_crop_u8(bg_u8, self.resize, self.crop[0], self.crop[1],
+                                   torch.tensor(list(tops), dtype=torch.int32).to(dev), torch.tensor(list(lefts), dtype=torch.int32).to(dev))
 
 
 class TrainClipFrontEnd:

@@ -726,15 +726,15 @@ class LSCLossFn(torch.autograd.Function):
     """libs/losses/lsc_loss.py:36-56; forward kernel also produces dsim and deta."""
 
     @staticmethod
-    def forward(ctx, sim, targets, eta, margin, hinge):
-        loss, dsim, deta = K.lsc_loss(sim.contiguous(), targets.contiguous(), eta, margin, hinge)
+    def forward(ctx, sim, targets, eta, margin, hinge, class_weights=None):
+        loss, dsim, deta = K.lsc_loss(sim.contiguous(), targets.contiguous(), eta, margin, hinge, class_weights)
         ctx.save_for_backward(dsim, deta)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         dsim, deta = ctx.saved_tensors
-        return _scale_by(g, dsim), None, (_scale_by(g, deta) if ctx.needs_input_grad[2] else None), None, None
+        return _scale_by(g, dsim), None, (_scale_by(g, deta) if ctx.needs_input_grad[2] else None), None, None, None
 
 
 class SoftCEFn(torch.autograd.Function):

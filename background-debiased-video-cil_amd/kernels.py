@@ -290,6 +290,14 @@ def conv_kernel_name(g: ConvGeom, kind: str, x3: Optional[bool] = None) -> str:
     return buf.value.decode()
 
 
+def conv_uses_planes(g: ConvGeom, kind: str) -> bool:
+    """True when ``conv_fprop`` / ``conv_dgrad`` of this geometry read the cached bf16 weight planes (the cache that
+    ``bump_weight_epoch`` invalidates) in the current arithmetic."""
+    k = {'fprop': 0, 'dgrad': 1}[kind]
+    flag = (FPROP_X3, DGRAD_X3)[k]
+    return bool(flag and USE_PL and lib().bdv_conv_uses_planes(ctypes.byref(g), k, PIECES))
+
+
 PRE_BN_1X1_ONLY = _os.environ.get('BDVCIL_PRE_BN_3X3', '0') == '0'
 
 
@@ -696,13 +704,15 @@ def avgpool_bwd(dout, in_shape, dtype=torch.float32):
 
 
 def bgmix_normalize_u8(frames, bg, mix, alpha, mean, std, want_nhwc4=True, want_nchw=False):
-    """frames (B,T,H,W,3) u8, bg (B,H,W,3) u8 | None, mix (B,) u8/bool | None."""
+    """frames (B,T,H,W,3) u8, bg (B,H,W,3) u8 -- or fp32 pixel values in [0,255], the output of ``bg_resize_crop_u8`` -- | None,
+    mix (B,) u8/bool | None."""
     _chk(frames, dtype=torch.uint8, name='frames')
     B, T, H, W, c3 = frames.shape
     if c3 != 3:
         raise ValueError('frames must be (B,T,H,W,3)')
+    bg_f32 = bg is not None and bg.dtype == torch.float32
     if bg is not None:
-        _chk(bg, (B, H, W, 3), dtype=torch.uint8, name='bg')
+        _chk(bg, (B, H, W, 3), dtype=torch.float32 if bg_f32 else torch.uint8, name='bg')
         mix = mix.to(torch.uint8) if mix.dtype != torch.uint8 else mix
         _chk(mix, (B,), dtype=torch.uint8, name='mix')
     else:
@@ -713,9 +723,35 @@ def bgmix_normalize_u8(frames, bg, mix, alpha, mean, std, want_nhwc4=True, want_
     inv = 1.0 / s      # fp32 reciprocal, as the CPU restatement computes it
     o4 = torch.empty((B * T, H, W, 4), dtype=torch.float32, device=frames.device) if want_nhwc4 else None
     oc = torch.empty((B, T, 3, H, W), dtype=torch.float32, device=frames.device) if want_nchw else None
-    check(lib().bdv_bgmix_normalize_u8(_p(frames), _p(bg), _p(mix), float(alpha), f3(*m.tolist()), f3(*s.tolist()),
+    check(lib().bdv_bgmix_normalize_u8(_p(frames), _p(bg), int(bg_f32), _p(mix), float(alpha), f3(*m.tolist()), f3(*s.tolist()),
                                        f3(*inv.tolist()), _p(o4), _p(oc), B, T, H, W, _stream()), 'bdv_bgmix_normalize_u8')
     return o4, oc
+
+
+def resized_size(h: int, w: int, size: int):
+    """Output size of torchvision's ``Resize(size)`` with an int: the smaller edge becomes ``size``, the other one
+    ``int(size * long / short)`` (UPSTREAM torchvision ``_compute_resized_output_size``)."""
+    short, long = (w, h) if w <= h else (h, w)
+    new_short, new_long = size, int(size * long / short)
+    return (new_long, new_short) if w <= h else (new_short, new_long)
+
+
+def bg_resize_crop_u8(bg, size, crop_h, crop_w, top, left):
+    """bg (B,Hs,Ws,3) u8 -> (B,crop_h,crop_w,3) fp32 in [0,255]: ``Resize(size)`` + crop at (top[b], left[b]) of
+    BackgroundMixDataset.bg_pipeline (libs/loader/comix_loader.py:72-73); top / left: (B,) int32 tensors on the device."""
+    _chk(bg, dtype=torch.uint8, name='bg')
+    if bg.dim() != 4 or bg.shape[-1] != 3:
+        raise ValueError(f'bg_resize_crop_u8: expected (B,Hs,Ws,3), got {tuple(bg.shape)}')
+    B, Hs, Ws, _ = bg.shape
+    Hr, Wr = resized_size(Hs, Ws, int(size))
+    if crop_h > Hr or crop_w > Wr:
+        raise ValueError(f'Required crop size {(crop_h, crop_w)} is larger than input image size {(Hr, Wr)}')     # torchvision's message
+    _chk(top, (B,), dtype=torch.int32, name='top')
+    _chk(left, (B,), dtype=torch.int32, name='left')
+    out = torch.empty((B, crop_h, crop_w, 3), dtype=torch.float32, device=bg.device)
+    check(lib().bdv_bg_resize_crop_u8(_p(bg), B, Hs, Ws, Hr, Wr, _p(top), _p(left), int(crop_h), int(crop_w), _p(out), _stream()),
+          'bdv_bg_resize_crop_u8')
+    return out
 
 
 def crop_normalize_u8(frames, crops, crop_h, crop_w, mean, std, want_nhwc4=True, want_nchw=False):
@@ -886,15 +922,17 @@ def dropout(x, p, seed):
     return out
 
 
-def lsc_loss(sim, targets, eta, margin, hinge):
+def lsc_loss(sim, targets, eta, margin, hinge, class_weights=None):
     _chk(sim, name='sim')
     B, K = sim.shape
     _chk(targets, (B,), dtype=torch.int64, name='targets')
     _chk(eta, (1,), name='eta')
+    if class_weights is not None:
+        _chk(class_weights, (K,), name='class_weights')
     out = torch.empty(2, dtype=torch.float32, device=sim.device)   # loss, deta
     dsim = torch.empty_like(sim)
-    check(lib().bdv_lsc_loss(_p(sim), _p(targets), _p(eta), float(margin), int(bool(hinge)), _p(out[0:1]), _p(dsim),
-                             _p(out[1:2]), B, K, _stream()), 'bdv_lsc_loss')
+    check(lib().bdv_lsc_loss(_p(sim), _p(targets), _p(eta), float(margin), int(bool(hinge)), _p(class_weights), _p(out[0:1]),
+                             _p(dsim), _p(out[1:2]), B, K, _stream()), 'bdv_lsc_loss')
     return out[0], dsim, out[1:2]
 
 

@@ -10,6 +10,29 @@ from . import kernels as K
 from .registry import LOSSES
 
 
+def _class_weights(cw, like: torch.Tensor):
+    """``class_weights`` as the reference accepts it (a tensor indexed by the targets, or anything ``F.cross_entropy`` takes as
+    ``weight``) -> contiguous fp32 (K,) on the scores' device, or None."""
+    if cw is None:
+        return None
+    cw = torch.as_tensor(cw, dtype=torch.float32).to(like.device).contiguous()
+    if cw.dim() != 1 or cw.numel() != like.shape[1]:
+        raise ValueError(f'class_weights: expected {like.shape[1]} values (one per class), got shape {tuple(cw.shape)}')
+    return cw
+
+
+def _weighted_ce(score, labels, cw):
+    """``F.cross_entropy(score, labels, weight=cw, reduction='mean')`` = sum_i w[y_i] * ce_i / sum_i w[y_i]: the soft-target kernel
+    on one-hot rows scaled by B * w[y_i] / sum_j w[y_j] (its mean over the batch is then the weighted mean)."""
+    labels = labels.contiguous()
+    if cw is None:
+        return Fn.SoftCEFn.apply(score, None, labels)
+    w = cw[labels]
+    rows = torch.zeros_like(score)
+    rows.scatter_(1, labels.view(-1, 1), (w * (labels.numel() / w.sum())).view(-1, 1))     # (B, K)-sized plumbing
+    return Fn.SoftCEFn.apply(score, rows, None)
+
+
 @LOSSES.register_module()
 class LSCLoss(nn.Module):
     """libs/losses/lsc_loss.py:8-58.  ``forward(similarities (B,K), targets (B,), **kwargs) -> scalar``."""
@@ -25,13 +48,12 @@ class LSCLoss(nn.Module):
         self.eta = nn.Parameter(torch.Tensor([eta]), requires_grad=self.learnable_eta)
 
     def forward(self, similarities: torch.Tensor, targets: torch.Tensor, **kwargs):
-        if self.class_weights is not None:
-            raise NotImplementedError('class_weights is None in every shipped config (SURVEY.md section 8); not on the HIP path')
         if targets.dim() == 0:
             targets = targets.unsqueeze(0)
+        cw = _class_weights(self.class_weights, similarities)
         if self.exclude_pos_denominator:
-            return Fn.LSCLossFn.apply(similarities, targets, self.eta, float(self.margin), bool(self.hinge_proxynca))
-        return Fn.SoftCEFn.apply(similarities, None, targets.contiguous())      # lsc_loss.py:58: plain cross entropy
+            return Fn.LSCLossFn.apply(similarities, targets, self.eta, float(self.margin), bool(self.hinge_proxynca), cw)
+        return _weighted_ce(similarities, targets, cw)                          # lsc_loss.py:58: (weighted) cross entropy
 
 
 @LOSSES.register_module()
@@ -42,14 +64,13 @@ class CrossEntropyLoss(nn.Module):
 
     def __init__(self, loss_weight=1.0, class_weight=None):
         super().__init__()
-        if class_weight is not None:
-            raise NotImplementedError('class_weight is not on the HIP path')
         self.loss_weight = loss_weight
+        self.class_weight = None if class_weight is None else torch.as_tensor(class_weight, dtype=torch.float32)   # UPSTREAM: a list
 
     def forward(self, cls_score, label, **kwargs):
         if label.dim() == 0:
             label = label.unsqueeze(0)
-        loss = Fn.SoftCEFn.apply(cls_score, None, label.contiguous())
+        loss = _weighted_ce(cls_score, label, _class_weights(self.class_weight, cls_score))
         return loss if self.loss_weight == 1.0 else loss * self.loss_weight
 
 

@@ -70,23 +70,36 @@ def class_means_from_repr(mean_crops_repr: torch.Tensor, label: torch.Tensor, nu
     return K.class_means(r, lab, num_classes)
 
 
+# Per-sample entries of a prediction dictionary (``predict_step`` output gathered over a class's training videos): tensors indexed
+# along dimension 0 by sample, plus the ``frame_dir`` list.  An exemplar entry keeps the second tuple's keys of the chosen samples.
+_SAMPLE_TENSOR_KEYS = ('total_frames', 'label', 'clip_len', 'num_clips', 'frame_inds', 'repr_', 'cls_score')
+_EXEMPLAR_TENSOR_KEYS = ('total_frames', 'label', 'clip_len', 'frame_inds')
+_STORING = {'videos': 3, 'clips': 4}        # storing method -> rank of ``repr_``: (videos, samples, dims) / (videos, clips, samples, dims)
+
+
+def _take(record: Dict, rows, tensor_keys) -> Dict:
+    """Sub-record of the samples ``rows`` (a list of ints or an index tensor)."""
+    picked = rows.tolist() if torch.is_tensor(rows) else list(rows)
+    out = {'frame_dir': [record['frame_dir'][r] for r in picked]}
+    out.update({k: record[k][rows] for k in tensor_keys})
+    return out
+
+
 class Herding:
-    """iCaRL herding with the reference's constructor, checks and result dictionary (memory_selection.py:7-164)."""
+    """iCaRL herding behind the interface of libs/cil/memory_selection.py:7-164: ``Herding(budget_size, class_indices,
+    cosine_distance, storing_methods, budget_type).construct_exemplar(prediction_with_meta)`` returns, per class index,
+    ``{'indices', 'dist', 'class_mean', 'frame_dir', 'total_frames', 'label', 'clip_len', 'frame_inds'}`` of the selected samples."""
 
     def __init__(self, budget_size: int, class_indices: List[int], cosine_distance: bool, storing_methods='clips',
                  budget_type='class'):
-        assert storing_methods in ['videos', 'clips', 'frames']
-        assert budget_type in ['fixed', 'class']
-        self.cosine_distance = cosine_distance
-        self.storing_methods = storing_methods
-        self.budget_type = budget_type
-        self.budget_size = budget_size
-        self.num_classes = len(class_indices)
+        assert storing_methods in ('videos', 'clips', 'frames'), storing_methods
+        assert budget_type in ('fixed', 'class'), budget_type
+        self.budget_size, self.budget_type = budget_size, budget_type
+        self.storing_methods, self.cosine_distance = storing_methods, cosine_distance
         self.class_indices = class_indices
-        if self.budget_type == 'fixed':
-            self.num_exemplars_per_class = budget_size // self.num_classes
-        else:
-            self.num_exemplars_per_class = budget_size
+        self.num_classes = len(class_indices)
+        # 'class': the budget is per class; 'fixed': one budget shared evenly by the classes seen so far
+        self.num_exemplars_per_class = budget_size if budget_type == 'class' else budget_size // self.num_classes
 
     # -- feature layout handling (memory_selection.py:50-69) --------------------------------------------------------
     def _class_features(self, features: torch.Tensor) -> torch.Tensor:
@@ -126,29 +139,23 @@ class Herding:
         return self._update_exemplar(exemplar_meta, meta_by_class)
 
     def _update_exemplar(self, exemplar_meta: dict, meta_by_class: dict):
-        for class_idx, meta in meta_by_class.items():
-            sample_indices = exemplar_meta[class_idx]['indices']
-            exemplar_meta[class_idx]['frame_dir'] = [meta['frame_dir'][i_] for i_ in sample_indices]
-            for key in ('total_frames', 'label', 'clip_len', 'frame_inds'):
-                exemplar_meta[class_idx][key] = meta[key][sample_indices]
+        """Attach the bookkeeping of the selected samples (what an exemplar annotation line is written from) to each class entry."""
+        for cls, chosen in exemplar_meta.items():
+            chosen.update(_take(meta_by_class[cls], chosen['indices'], _EXEMPLAR_TENSOR_KEYS))
         return exemplar_meta
 
     def _check_dimension(self, all_features, labels):
         if all_features.size(0) != labels.size(0):
             raise ValueError('all_features and labels must have the same value of dim 0')
-        if self.storing_methods == 'videos' and len(all_features.shape) != 3:
-            raise ValueError('Expecting 3D features: (videos, samples, dims)')
-        if self.storing_methods == 'clips' and len(all_features.shape) != 4:
-            raise ValueError('Expecting 4D features: (videos, clips, samples, dims)')
-        if self.storing_methods == 'frames':
+        want = _STORING.get(self.storing_methods)
+        if want is None:                                    # 'frames' passes the constructor, as in the reference, and stops here
             raise NotImplementedError('frame herding not supported yet')
+        if all_features.dim() != want:
+            layout = '(videos, samples, dims)' if want == 3 else '(videos, clips, samples, dims)'
+            raise ValueError(f'Expecting {want}D features: {layout}')
 
     def split_meta_by_class(self, prediction_with_meta: dict):
-        frame_dir = prediction_with_meta['frame_dir']
-        meta_by_class = {}
-        for i in self.class_indices:
-            indices = (prediction_with_meta['label'] == i).nonzero(as_tuple=True)[0]
-            meta_by_class[i] = {'frame_dir': [frame_dir[idx] for idx in indices]}
-            for key in ('total_frames', 'label', 'clip_len', 'num_clips', 'frame_inds', 'repr_', 'cls_score'):
-                meta_by_class[i][key] = prediction_with_meta[key][indices]
-        return meta_by_class
+        """{class index: the per-sample entries of that class's samples}, in ``class_indices`` order."""
+        labels = prediction_with_meta['label']
+        return {c: _take(prediction_with_meta, torch.nonzero(labels == c, as_tuple=True)[0], _SAMPLE_TENSOR_KEYS)
+                for c in self.class_indices}

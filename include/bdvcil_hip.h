@@ -156,7 +156,8 @@ int bdv_conv_dgrad_x3(const float* dy, const float* w, const float* w_t, float* 
 size_t bdv_conv_weight_planes_bytes(const bdv_conv_geom* g);
 int bdv_conv_split_weights(const float* w, const bdv_conv_geom* g, void* planes_fprop, void* planes_dgrad, void* stream);
 /* Test / A-B hook, process-wide and not thread-safe: force the tile configuration of the two entry points below
- * (0 = 128x256, 1 = 256x128, 2 = 256x256, 3 = 256x64, where the tile divides the column count; -1 = the planner's rules). */
+ * (0 = 128x256, 1 = 256x128, 2 = 256x256, 3 = 256x64, 4 = 64x128 (dgrad, stride 1), 5 = 128x128 with four waves and two
+ * workgroups per CU, where the tile divides the column count; 6 = none of them; -1 = the planner's rules). */
 int bdv_conv_debug_force_tile(int cfg);
 /* 1 when bdv_conv_fprop_pl (kind 0) / bdv_conv_dgrad_pl (kind 1) will read the weight planes for this geometry, 0 when it
  * runs a kernel that takes w (the caller then need not build the planes). */
@@ -295,12 +296,20 @@ int bdv_avgpool_bwd(const float* dout, void* dx, int N, int HW, int C, int act_d
 
 /* ---- fused background-mix / normalize front-end -------------------------------------------
  * libs/loader/comix_loader.py:72-75,138-145 + UPSTREAM Normalize (img_norm_cfg, config :121-122).
- * frames (B,T,H,W,3) uint8 RGB, bg (B,H,W,3) uint8, mix (B) uint8 {0,1};
+ * frames (B,T,H,W,3) uint8 RGB, bg (B,H,W,3) uint8 -- or fp32 pixel values in [0,255] when bg_f32 != 0 (the
+ * output of bdv_bg_resize_crop_u8) --, mix (B) uint8 {0,1};
  * out_nhwc4 (B*T,H,W,4) and/or out_nchw (B,T,3,H,W) (either may be NULL).
  * frame: (x-mean)*inv_std ; bg: (x-mean)/std ; blend x*(1-alpha)+bg*alpha where mix[b] != 0. */
-int bdv_bgmix_normalize_u8(const uint8_t* frames, const uint8_t* bg, const uint8_t* mix, float alpha,
+int bdv_bgmix_normalize_u8(const uint8_t* frames, const void* bg, int bg_f32, const uint8_t* mix, float alpha,
                            const float mean[3], const float std[3], const float inv_std[3],
                            float* out_nhwc4, float* out_nchw, int B, int T, int H, int W, void* stream);
+/* The stages of BackgroundMixDataset.bg_pipeline before Normalize (libs/loader/comix_loader.py:72-73): torchvision
+ * Resize(bg_resize) of the float image (smaller edge -> bg_resize; bilinear, align_corners=False, no antialias filter:
+ * the same values as the antialiased form when the image is enlarged) and RandomCrop(bg_crop_size) at the offsets the
+ * caller drew.  src: B uint8 RGB images (Hs,Ws,3) of one size; (Hr,Wr): the resized size; top / left: (B) int32 on the
+ * device; out: (B,crop_h,crop_w,3) fp32 pixel values in [0,255] (not rounded, as the reference's float image). */
+int bdv_bg_resize_crop_u8(const uint8_t* src, int B, int Hs, int Ws, int Hr, int Wr, const int32_t* top,
+                          const int32_t* left, int crop_h, int crop_w, float* out, void* stream);
 /* Test-time crops + normalize (val/test pipelines, configs/...bgmix_plus_randAug.py:140-171): CenterCrop / ThreeCrop /
  * TenCrop as emitted by the crop transforms (the reference's own libs/pipelines/five_crops.py:77-100 shows the offset
  * rule and the crop-major order; TenCrop adds the horizontally flipped copy of each crop right after it).
@@ -334,9 +343,10 @@ int bdv_dropout(const float* x, float* out, int64_t numel, float p, uint64_t see
 
 /* ---- fused losses -------------------------------------------------------------------------- */
 /* libs/losses/lsc_loss.py:30-58 (exclude_pos_denominator, optional hinge).  Writes loss (1),
- * dsim (B,K) and deta (1) for upstream gradient 1; callers scale. */
+ * dsim (B,K) and deta (1) for upstream gradient 1; callers scale.  `class_weights` (K) or NULL:
+ * lsc_loss.py:50-51, the row's term is scaled by class_weights[target] before the negation and the hinge. */
 int bdv_lsc_loss(const float* sim, const int64_t* targets, const float* eta, float margin, int hinge,
-                 float* loss, float* dsim, float* deta, int B, int K, void* stream);
+                 const float* class_weights, float* loss, float* dsim, float* deta, int B, int K, void* stream);
 /* libs/cil/icarl.py:123-125 soft-target CE: loss = mean_b(-sum_k tgt*log_softmax(score)).
  * `soft_targets` (B,K) or NULL with integer `labels` (B) (= plain mean cross-entropy). */
 int bdv_softce_loss(const float* score, const float* soft_targets, const int64_t* labels, float* loss,

@@ -467,6 +467,23 @@ def bgmix_normalize(frames_u8: torch.Tensor, bg_u8: torch.Tensor, mix_mask: torc
     return out.permute(0, 1, 4, 2, 3).contiguous()
 
 
+def bg_resize_crop(bg_u8: torch.Tensor, resize: int, crop: int, top: int, left: int, antialias: bool = False) -> torch.Tensor:
+    """One background image through ``Resize(resize) -> RandomCrop(crop)`` of BackgroundMixDataset.bg_pipeline
+    (libs/loader/comix_loader.py:72-73) at the given crop offsets.  bg_u8 (Hs,Ws,3) uint8 -> (crop,crop,3) fp32 in [0,255].
+    UPSTREAM torchvision (not importable here, version unpinned by the reference: PARITY UNPINNED): ``Resize`` with an int
+    makes the smaller edge ``resize`` and the other ``int(resize * long / short)``; on a float tensor image (the reference
+    passes ``read_image(...).float()``, comix_loader.py:128,134) it is ``F.interpolate(mode='bilinear', align_corners=False)``
+    without rounding; ``antialias`` only matters when the image shrinks (torchvision's default changed over versions)."""
+    import torch.nn.functional as F
+    h, w = bg_u8.shape[:2]
+    short, long = (w, h) if w <= h else (h, w)
+    new_short, new_long = resize, int(resize * long / short)
+    nh, nw = (new_long, new_short) if w <= h else (new_short, new_long)
+    img = bg_u8.permute(2, 0, 1).float().unsqueeze(0)                       # read_image gives (3,H,W); .float()
+    out = F.interpolate(img, size=(nh, nw), mode='bilinear', align_corners=False, antialias=antialias)[0]
+    return out[:, top:top + crop, left:left + crop].permute(1, 2, 0).contiguous()
+
+
 # ---------------------------------------------------------------------------------------
 # optimizer param groups (reference: libs/models/cil_heads/tsm.py:211-303) + step
 # ---------------------------------------------------------------------------------------

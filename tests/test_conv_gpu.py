@@ -398,7 +398,7 @@ PL_CASES = [
 
 
 @pytest.mark.parametrize('case', PL_CASES)
-@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 3, 4, 5])
 def test_plane_kernels_every_tile(case, tile, dev):
     """The 8-wave kernels on pre-split weight planes (bdv_conv_fprop_pl / bdv_conv_dgrad_pl), every tile configuration
     forced in turn (-1 = planner's choice): against the CPU reference (2e-5), against the fp32-MFMA kernels (4e-6), with the

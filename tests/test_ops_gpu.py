@@ -131,6 +131,84 @@ def test_bgmix_frontend(alpha, dev):
     assert torch.equal(o4n.cpu()[..., :3].reshape(B, T, H, W, 3).permute(0, 1, 4, 2, 3), refn)
 
 
+@pytest.mark.parametrize('Hs,Ws', [(240, 320), (256, 340), (320, 240), (360, 480)])
+def test_bg_resize_crop_into_the_mix(Hs, Ws, dev):
+    """``Resize(256) -> RandomCrop(224)`` of the background pipeline (libs/loader/comix_loader.py:72-73) in one kernel, and its fp32
+    output through the fused Normalize + blend.  Oracle: torch ``F.interpolate`` on the float image (what torchvision's Resize calls;
+    PARITY UNPINNED: torchvision is not importable and its version is not pinned by the reference).  Bars: 1e-4 of a grey level for
+    the resampled pixels (fp32 interpolation weights, summation order), 2e-5 of scale after the blend; offsets are drawn in
+    torchvision's order from torch's global generator.  A 360 x 480 image SHRINKS: the kernel implements the filter-free form
+    (torchvision < 0.17 default); the oracle is called with antialias=False there."""
+    import bdvcil_amd as bd
+    from bdvcil_amd import kernels as K
+    B, T = 3, 2
+    gen = torch.Generator().manual_seed(Hs + Ws)
+    bg = torch.randint(0, 256, (B, Hs, Ws, 3), generator=gen, dtype=torch.uint8)
+    fe = bd.BackgroundCropFrontEnd(256, (224, 224))
+    Hr, Wr = K.resized_size(Hs, Ws, 256)
+    assert min(Hr, Wr) == 256 and (Hr, Wr) == ((256, int(256 * Ws / Hs)) if Hs <= Ws else (int(256 * Hs / Ws), 256))
+    torch.manual_seed(11)
+    tops, lefts = fe.draw(B, Hr, Wr)
+    torch.manual_seed(11)                                   # the draws of torchvision.transforms.RandomCrop.get_params, in its order
+    want = []
+    for _ in range(B):
+        i = int(torch.randint(0, Hr - 224 + 1, size=(1,)).item())
+        j = int(torch.randint(0, Wr - 224 + 1, size=(1,)).item())
+        want.append((i, j))
+    assert list(zip(tops, lefts)) == want
+    torch.manual_seed(11)
+    out = fe(bg.to(dev))
+    assert out.shape == (B, 224, 224, 3) and out.dtype == torch.float32
+    ref = torch.stack([O.bg_resize_crop(bg[b], 256, 224, tops[b], lefts[b]) for b in range(B)])
+    assert (out.cpu() - ref).abs().max().item() <= 1e-4
+    if min(Hs, Ws) <= 256:                                  # enlarging: the antialiased form (newer torchvision default) is the same image
+        ref_aa = torch.stack([O.bg_resize_crop(bg[b], 256, 224, tops[b], lefts[b], antialias=True) for b in range(B)])
+        assert (ref_aa - ref).abs().max().item() <= 1e-4
+    # through Normalize + blend, against the reference's formula on the oracle's crop
+    fr = torch.randint(0, 256, (B, T, 224, 224, 3), generator=gen, dtype=torch.uint8)
+    mix = torch.tensor([True, False, True])
+    o4 = bd.BackgroundMixFrontEnd(alpha=0.5)(fr.to(dev), out, mix.to(dev)).data
+    m, s_ = torch.tensor(O.IMG_MEAN), torch.tensor(O.IMG_STD)
+    x = (fr.float() - m) * (1.0 / s_)
+    blend = x * 0.5 + ((ref - m) / s_)[:, None] * 0.5
+    want_o = torch.where(mix.view(-1, 1, 1, 1, 1), blend, x)
+    got = o4.cpu()[..., :3].reshape(B, T, 224, 224, 3)
+    assert (got - want_o).abs().max().item() <= 2e-5 * want_o.abs().max().item()
+    with pytest.raises(ValueError):
+        bd.BackgroundCropFrontEnd(200, (224, 224))(bg.to(dev))          # torchvision: crop larger than the resized image
+
+
+def test_stale_weight_planes_are_caught_and_refreshed(dev, monkeypatch):
+    """A conv weight written through ``.data`` does not move torch's version counter: the cached bf16 planes stay stale and the
+    convolution silently runs on the OLD weights.  ``bump_weight_epoch()`` is the required call after such a write (INTEGRATION.md);
+    BDVCIL_CHECK_PLANES=1 turns the silent case into an error."""
+    import bdvcil_amd as bd
+    from bdvcil_amd import kernels as K
+    g = K.make_geom(8, 14, 14, 128, 256, 1, 1, 1, 0)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 14, 14, 128, generator=gen).to(dev)
+    from bdvcil_amd import functional as Fn
+    w = torch.nn.Parameter((torch.randn(256, 128, 1, 1, generator=gen) / 11.3).to(dev).contiguous(memory_format=torch.channels_last))
+    conv = lambda: K.conv_fprop(x, Fn.weight_krsc(w), g)      # noqa: E731  (the (Cout,R,S,Cin) view the model passes: cache key = the parameter)
+    assert K.conv_uses_planes(g, 'fprop')
+    y0 = conv()
+    w.data.mul_(2.0)                                          # torch does not see this write
+    stale = conv()
+    assert torch.equal(stale, y0)                             # the documented hazard: old planes, old result
+    bd.bump_weight_epoch()
+    fresh = conv()
+    assert (fresh - 2 * y0).abs().max().item() <= 2e-5 * (2 * y0).abs().max().item()
+    monkeypatch.setattr(K, 'CHECK_PLANES', True)
+    bd.bump_weight_epoch()
+    conv()                                                    # planes cut with a checksum
+    w.data.mul_(0.5)
+    with pytest.raises(RuntimeError, match='stale weight planes'):
+        conv()
+    bd.bump_weight_epoch([w])
+    back = conv()
+    assert (back - y0).abs().max().item() <= 2e-5 * y0.abs().max().item()
+
+
 def test_lsc_and_loss_vs_golden(dev):
     """Golden vectors generated from the reference's own cosine_linear.py / lsc_loss.py."""
     from bdvcil_amd import kernels as K
@@ -156,6 +234,35 @@ def test_lsc_and_loss_vs_golden(dev):
     _close(loss.reshape(()), torch.from_numpy(gz['hinge_loss']))
     _close(dsim, torch.from_numpy(gz['hinge_dsim']), tol=1e-4, atol=1e-7)
     _close(deta, torch.from_numpy(gz['hinge_deta']), tol=1e-4, atol=1e-7)
+
+
+def test_lsc_loss_class_weights_vs_golden(dev):
+    """``LSCLoss(class_weights=...)`` in both branches of libs/losses/lsc_loss.py (:50-51 the NCA form, :58 weighted cross entropy),
+    incl. a negative weight behind the hinge: values and gradients from the reference's own file (make_golden_lsc_weights.py)."""
+    import os
+    import bdvcil_amd as bd
+    gz = np.load(os.path.join(os.path.dirname(GOLD), 'lsc_weights_golden.npz'))
+    for i in range(int(gz['n'])):
+        p = f'c{i}_'
+        nca, hinge = (bool(v) for v in gz[p + 'cfg'])
+        sim = torch.from_numpy(gz[p + 'sim']).to(dev).requires_grad_(True)
+        y = torch.from_numpy(gz[p + 'y']).to(dev)
+        crit = bd.LSCLoss(eta=float(gz[p + 'eta']), exclude_pos_denominator=nca, hinge_proxynca=hinge,
+                          class_weights=torch.from_numpy(gz[p + 'cw'])).to(dev)
+        loss = crit(sim, y)
+        loss.backward()
+        _close(loss.detach().reshape(()), torch.from_numpy(gz[p + 'loss']), tol=1e-5)
+        _close(sim.grad, torch.from_numpy(gz[p + 'dsim']), tol=1e-4, atol=1e-7)
+        if nca:
+            _close(crit.eta.grad, torch.from_numpy(gz[p + 'deta']), tol=1e-4, atol=1e-6)
+    # the mmaction-style CrossEntropyLoss(class_weight=[...]) is the same weighted mean
+    g = torch.Generator().manual_seed(9)
+    score = torch.randn(6, 5, generator=g)
+    lab = torch.randint(0, 5, (6,), generator=g)
+    cw = [0.5, 2.0, 1.0, 0.25, 3.0]
+    ref = torch.nn.functional.cross_entropy(score, lab, weight=torch.tensor(cw))
+    got = bd.CrossEntropyLoss(class_weight=cw)(score.to(dev), lab.to(dev))
+    _close(got.reshape(()), ref.reshape(()), tol=1e-5)
 
 
 def test_linear_vs_golden(dev):

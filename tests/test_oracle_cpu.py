@@ -223,3 +223,18 @@ def test_i3d_oracle_and_plugin_surface():
     assert sum(p.numel() for p in mod.parameters()) == sum(p.numel() for p in ref.parameters()) == 27223872 + 2048 * 400 + 400
     with pytest.raises(FileNotFoundError):
         bd.build_model(dict(cfg, backbone=dict(cfg['backbone'], pretrained='torchvision://resnet50')))
+
+
+def test_bg_resize_crop_oracle_sizes_and_antialias():
+    """``O.bg_resize_crop`` (Resize(256) -> RandomCrop(224) of libs/loader/comix_loader.py:72-73): torchvision's output-size rule,
+    the crop window, and the fact the build relies on -- enlarging an image, the antialiased and the plain bilinear forms coincide."""
+    g = torch.Generator().manual_seed(0)
+    for (h, w) in [(240, 320), (320, 240), (256, 256)]:
+        img = torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8)
+        a = O.bg_resize_crop(img, 256, 224, 3, 5)
+        b = O.bg_resize_crop(img, 256, 224, 3, 5, antialias=True)
+        assert a.shape == (224, 224, 3) and a.dtype == torch.float32
+        assert (a - b).abs().max().item() <= 1e-4
+        assert 0.0 <= float(a.min()) and float(a.max()) <= 255.0
+    same = torch.randint(0, 256, (256, 300, 3), generator=g, dtype=torch.uint8)        # smaller edge already 256: Resize is the identity
+    assert torch.equal(O.bg_resize_crop(same, 256, 224, 0, 10), same[0:224, 10:234].float())

@@ -18,15 +18,15 @@ from tools.bench_conv import SHAPES, timeit  # noqa: E402
 N = int(os.environ.get('N', 256))
 FUSED = os.environ.get('FUSED', '0') == '1'
 dev = torch.device('cuda:0')
-CFG = {0: '128x256', 1: '256x128', 2: '256x256', 3: '256x64', 4: '64x128'}
+CFG = {0: '128x256', 1: '256x128', 2: '256x256', 3: '256x64', 4: '64x128', 5: '128x128'}
 
 
 def applicable(c, ncols):
-    bn = {0: 256, 1: 128, 2: 256, 3: 64, 4: 128}[c]
+    bn = {0: 256, 1: 128, 2: 256, 3: 64, 4: 128, 5: 128}[c]
     return ncols % bn == 0
 
 
-print(f'{"site":30s} dir    {"r1 x3":>8s} {"r1 planes":>9s} ' + ' '.join(f'{CFG[c]:>8s}' for c in range(5)) + '   best')
+print(f'{"site":30s} dir    {"r1 x3":>8s} {"r1 planes":>9s} ' + ' '.join(f'{CFG[c]:>8s}' for c in range(6)) + '   best')
 tot = {}
 for (Cin, Cout, k, st, H, cnt, sh) in SHAPES:
     if Cin % 32 != 0:
@@ -51,10 +51,10 @@ for (Cin, Cout, k, st, H, cnt, sh) in SHAPES:
         K.USE_PL = False
         t_old = timeit(fn)
         K.USE_PL = True
-        check(lib().bdv_conv_debug_force_tile(5), 'force')      # two-workgroup kernels with the weights from the planes
+        check(lib().bdv_conv_debug_force_tile(6), 'force')      # two-workgroup kernels with the weights from the planes
         t_r1p = timeit(fn)
         ts = {}
-        for c in range(5):
+        for c in range(6):
             if not applicable(c, ncols) or (c == 4 and (name != 'dgrad' or st != 1)):
                 continue
             check(lib().bdv_conv_debug_force_tile(c), 'force')
@@ -63,7 +63,7 @@ for (Cin, Cout, k, st, H, cnt, sh) in SHAPES:
         t_auto = timeit(fn)
         best = min([('r1', t_old), ('r1p', t_r1p)] + [(CFG[c], t) for c, t in ts.items()], key=lambda q: q[1])
         row = f'{str((Cin, Cout, k, st, H)):26s} x{cnt:<2d} {name}  {t_old:8.3f} {t_r1p:9.3f} ' + ' '.join(
-            f'{ts[c]:8.3f}' if c in ts else f'{"-":>8s}' for c in range(5)) + f'   {best[0]:8s} auto {t_auto:.3f}'
+            f'{ts[c]:8.3f}' if c in ts else f'{"-":>8s}' for c in range(6)) + f'   {best[0]:8s} auto {t_auto:.3f}'
         print(row, flush=True)
         for key, t in [('r1', t_old), ('r1p', t_r1p), ('auto', t_auto), ('best', best[1])]:
             tot[(name, key)] = tot.get((name, key), 0.0) + t * cnt
