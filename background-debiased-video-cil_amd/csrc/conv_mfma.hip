@@ -357,7 +357,9 @@ __device__ __forceinline__ void staged_epilogue(const f32x16 (&acc)[BM / WM / 32
 
 // DERIVE: the ReLU sign of the statistics may come from the conv output itself (BnStat::rscale); compiled out of the fp32-MFMA
 // kernels, whose 168-register budget has no room for it (the model only derives signs in the bf16-piece arithmetic).
-template <int BM, int BN, int WM, int WN, bool DERIVE = true, int ES = 4, class RowMap>
+// PIPE: two register sets, the loads of batch b + 1 issued before batch b is combined and stored (see below); only for kernels
+// whose register budget has room beside the accumulators (64 accumulator registers, <= 2 waves per SIMD).
+template <int BM, int BN, int WM, int WN, bool DERIVE = true, int ES = 4, bool PIPE = false, class RowMap>
 __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ smem, int tid,
                                                void* __restrict__ dx, const void* __restrict__ add_src,
                                                const uint32_t* __restrict__ add_mask, const Geom& g, int mt, int nt, int Mrows,
@@ -387,6 +389,74 @@ __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32]
   const int cls = shift_class(col, g.fold);
   StatAcc sa;
   if (do_stat) sa.init(stat, col);
+  // The pieces of a tile are handled in batches of HB (register budget: 2 float4 + 3 words per piece and set); a batch's global
+  // loads (residual, its mask, the statistics operand and its mask) do not depend on the staged tile, so the loads of batch b + 1
+  // are issued BEFORE batch b is combined and stored (two register sets): the tile pays one load latency instead of one per batch.
+  // Round 2 issued load -> combine -> store batch by batch; the buffer stores of a batch and the loads of the next one may alias
+  // (in-place add_src), so the compiler could not hoist them itself: in-kernel stamps put the epilogue of the conv1 sites at
+  // 12 - 17 us beside a K loop of 18 us (tools/stamp_tiles.py).  No hazard is created: a batch reads and writes only its own
+  // pieces, and every dx element is written exactly once.
+  constexpr int HB = PER < 4 ? PER : 4;  // pieces in flight per thread and register set
+  constexpr int NBATCH = PER / HB;       // batches per pass
+  static_assert(PER % HB == 0, "pieces per pass must be whole batches");
+  constexpr int NSETS = PIPE ? 2 : 1;
+  float4 a[NSETS][HB], yv[NSETS][HB];
+  uint32_t am[NSETS][HB], sm[NSETS][HB];
+  int off[NSETS][HB];
+  bool zero[NSETS][HB];
+  auto issue = [&](int set, int i, int q0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < HB; ++u) {
+      const int lr = (tid + NT * (q0 + u)) / V;
+      const int mrow = mt * BM + 32 * WM * i + lr;
+      const bool ok = mrow < Mrows;
+      const int row = rowmap(ok ? mrow : 0);
+      int drow = row;
+      bool z = false;
+      if (cls != 0) {  // temporal un-shift: frame n -> n + cls inside the clip, else the zero the far clip end needs
+        int n, rem;
+        fast_divmod(row, HW, rcp_HW, n, rem);
+        const int t = n % g.T;
+        const bool inside = (unsigned)(t + cls) < (unsigned)g.T;
+        drow = inside ? row + cls * HW : row - cls * (g.T - 1) * HW;
+        z = !inside;
+      }
+      const int o = drow * g.Cin + col;
+      off[set][u] = ok ? o * ES : kOOB;
+      zero[set][u] = z;
+      a[set][u] = buf_ld4<ES>(adr, off[set][u]);  // zeros when there is no add_src
+      am[set][u] = add_mask ? __builtin_amdgcn_raw_buffer_load_b32(amr, ok ? (o >> 5) << 2 : kOOB, 0, 0) : 0xffffffffu;
+      if (do_stat) {
+        yv[set][u] = buf_ld4<ES>(syr, off[set][u]);
+        sm[set][u] = stat.mask ? __builtin_amdgcn_raw_buffer_load_b32(smr, ok ? (o >> 5) << 2 : kOOB, 0, 0) : 0xffffffffu;
+      }
+    }
+  };
+  auto finish = [&](int set, int q0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < HB; ++u) {
+      const int lr = (tid + NT * (q0 + u)) / V;
+      const float4 t4 = *reinterpret_cast<const float4*>(smem + lr * BN + 4 * (tid % V));
+      const int sh = (off[set][u] / ES) & 31;  // bit position of the piece's first channel in its mask word
+      const unsigned nib = (am[set][u] >> sh) & 0xFu;
+      float4 r = zero[set][u] ? make_float4(0.f, 0.f, 0.f, 0.f) : t4;
+      r.x += (nib & 1u) ? a[set][u].x : 0.f;
+      r.y += (nib & 2u) ? a[set][u].y : 0.f;
+      r.z += (nib & 4u) ? a[set][u].z : 0.f;
+      r.w += (nib & 8u) ? a[set][u].w : 0.f;
+      buf_st4<ES>(dxr, off[set][u], r);
+      if (do_stat && off[set][u] != kOOB) {
+        const unsigned sn = (DERIVE && stat.rscale != nullptr) ? StatAcc::sign_bits(stat, col, yv[set][u]) : (sm[set][u] >> sh) & 0xFu;
+        float4 gq;
+        gq.x = (sn & 1u) ? r.x : 0.f;
+        gq.y = (sn & 2u) ? r.y : 0.f;
+        gq.z = (sn & 4u) ? r.z : 0.f;
+        gq.w = (sn & 8u) ? r.w : 0.f;
+        sa.accumulate(gq, yv[set][u]);
+      }
+    }
+  };
+  if constexpr (PIPE) issue(0, 0, 0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     __syncthreads();  // LDS is free: K loop / previous pass finished
@@ -395,58 +465,15 @@ __device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[BM / WM / 32]
 #pragma unroll
       for (int e = 0; e < 16; ++e) smem[(wm * 32 + acc_row(e, lane)) * BN + wn0 + 32 * WN * j + (lane & 31)] = acc[i][j][e];
     __syncthreads();
-    constexpr int HB = PER < 4 ? PER : 4;  // pieces in flight per thread (register budget: 3 float4 + 3 words each)
 #pragma unroll
-    for (int q0 = 0; q0 < PER; q0 += HB) {
-      float4 v[HB], a[HB], yv[HB];
-      uint32_t am[HB], sm[HB];
-      int off[HB];
-#pragma unroll
-      for (int u = 0; u < HB; ++u) {
-        const int lr = (tid + NT * (q0 + u)) / V;
-        const int mrow = mt * BM + 32 * WM * i + lr;
-        const bool ok = mrow < Mrows;
-        const int row = rowmap(ok ? mrow : 0);
-        int drow = row;
-        bool zero = false;
-        if (cls != 0) {  // temporal un-shift: frame n -> n + cls inside the clip, else the zero the far clip end needs
-          int n, rem;
-          fast_divmod(row, HW, rcp_HW, n, rem);
-          const int t = n % g.T;
-          const bool inside = (unsigned)(t + cls) < (unsigned)g.T;
-          drow = inside ? row + cls * HW : row - cls * (g.T - 1) * HW;
-          zero = !inside;
-        }
-        const int o = drow * g.Cin + col;
-        off[u] = ok ? o * ES : kOOB;
-        const float4 t4 = *reinterpret_cast<const float4*>(smem + lr * BN + 4 * (tid % V));
-        v[u] = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : t4;
-        a[u] = buf_ld4<ES>(adr, off[u]);  // zeros when there is no add_src
-        am[u] = add_mask ? __builtin_amdgcn_raw_buffer_load_b32(amr, ok ? (o >> 5) << 2 : kOOB, 0, 0) : 0xffffffffu;
-        if (do_stat) {
-          yv[u] = buf_ld4<ES>(syr, off[u]);
-          sm[u] = stat.mask ? __builtin_amdgcn_raw_buffer_load_b32(smr, ok ? (o >> 5) << 2 : kOOB, 0, 0) : 0xffffffffu;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < HB; ++u) {
-        const int sh = (off[u] / ES) & 31;  // bit position of the piece's first channel in its mask word
-        const unsigned nib = (am[u] >> sh) & 0xFu;
-        float4 r = v[u];
-        r.x += (nib & 1u) ? a[u].x : 0.f;
-        r.y += (nib & 2u) ? a[u].y : 0.f;
-        r.z += (nib & 4u) ? a[u].z : 0.f;
-        r.w += (nib & 8u) ? a[u].w : 0.f;
-        buf_st4<ES>(dxr, off[u], r);
-        if (do_stat && off[u] != kOOB) {
-          const unsigned sn = (DERIVE && stat.rscale != nullptr) ? StatAcc::sign_bits(stat, col, yv[u]) : (sm[u] >> sh) & 0xFu;
-          float4 gq;
-          gq.x = (sn & 1u) ? r.x : 0.f;
-          gq.y = (sn & 2u) ? r.y : 0.f;
-          gq.z = (sn & 4u) ? r.z : 0.f;
-          gq.w = (sn & 8u) ? r.w : 0.f;
-          sa.accumulate(gq, yv[u]);
-        }
+    for (int bq = 0; bq < NBATCH; ++bq) {
+      if constexpr (PIPE) {
+        const int b = i * NBATCH + bq;                     // compile-time after unrolling
+        if (b + 1 < TM * NBATCH) issue((b + 1) & 1, (b + 1) / NBATCH, ((b + 1) % NBATCH) * HB);
+        finish(b & 1, bq * HB);
+      } else {                                             // round-2 order: load, combine, store, batch by batch
+        issue(0, i, bq * HB);
+        finish(0, bq * HB);
       }
     }
   }
@@ -1419,7 +1446,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_x3_kernel(const float* __re
   // frame n + cls when that frame is inside the clip.  Rows whose target falls outside the clip
   // ("orphans") instead write the zero that the unreachable frame at the other clip end needs,
   // which makes the scatter a bijection over dx.
-  dgrad_epilogue<BM, BN, WM, WN>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
+  dgrad_epilogue<BM, BN, WM, WN, true, 4, true>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
     if (st == 1) return mrow;
     const int n = mrow / HcWc;
     const int rem = mrow - n * HcWc;
@@ -2392,7 +2419,8 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM *
     store_partial<TM, TN, NTHR>(slab, it.pslot, acc, tid);
     return;
   }
-  dgrad_epilogue<BM, BN, WM, WN, true, ES>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
+  constexpr bool EPI_PIPE = TM * TN <= 4 && NP == 3 && BM != 64;   // 64 accumulator registers, two waves per SIMD
+  dgrad_epilogue<BM, BN, WM, WN, true, ES, EPI_PIPE>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
     if (st == 1) return mrow;
     const int n = mrow / HcWc;
     const int rem = mrow - n * HcWc;
