@@ -69,88 +69,73 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-// Fixed-order column sum of two [RB][C] fp32 slabs in fp64.  A block of 1024 threads owns 16 channels: thread = (row lane
-// rl = tid / 4, float4 column tid % 4), so that a row of the block's slice is ONE 64-byte access shared by four lanes (round 2
-// read 4 bytes per lane, a quarter of every sector fetched: 12 us on average and 88 us for the stem's 25 088 partial rows, 106
-// launches per step on the dependent chain).  The loop is a chain of dependent-latency loads, so the rows are spread over 256
-// lanes per channel with four independent chains each; the lane sums are combined in a fixed order (16 groups of 16).  The order
-// of every channel's sum is exactly the round-2 kernel's: results are bit-identical.
+// Fixed-order column sum of two [RB][C] fp32 slabs in fp64: 4 channels x FIN_LANES row-lanes per block (1024 threads).
+// (Round 3 tried 16 channels per block with 16-byte row accesses -- a quarter of the memory transactions, the same summation order:
+// 16.1 / 12.9 us per launch against 12.3 / 10.0 us for this form in the same profile; the kernel is bound by its fp64 adds and the
+// load latency chain, which four times fewer blocks concentrate on four times fewer CUs.  Reverted; profiles/r03_notes.md.)
+// The loop is a chain of dependent-latency loads (up to 25 088 partial rows for the stem), so the rows are spread over 256
+// lanes per channel with four independent chains each; the lane sums are combined in a fixed order (16 groups of 16).
 constexpr int FIN_LANES = 256;
-constexpr int FIN_CH = 16;      // channels per block
 
-struct dbl4 {
-  double x, y, z, w;
-};
-__device__ __forceinline__ void acc4(dbl4& a, const float4 v) {
-  a.x += (double)v.x; a.y += (double)v.y; a.z += (double)v.z; a.w += (double)v.w;
-}
-__device__ __forceinline__ dbl4 tree4(const dbl4& a, const dbl4& b, const dbl4& c, const dbl4& d) {
-  return {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
-}
-
-// sh: [2][FIN_LANES][FIN_CH + 1] doubles.  On return the threads with rl == 0 hold the sums of their four channels in sa / sb.
-__device__ __forceinline__ void slab_colsum2(const float* __restrict__ a, const float* __restrict__ b, int RB, int C, int c0,
-                                             int rl, int cq, double (*sh)[FIN_LANES][FIN_CH + 1], dbl4& sa, dbl4& sb) {
-  const dbl4 zero = {0.0, 0.0, 0.0, 0.0};
-  dbl4 x = zero, y = zero;
-  if (c0 < C) {
-    dbl4 x1 = zero, x2 = zero, x3 = zero, y1 = zero, y2 = zero, y3 = zero;
-    const float4* ap = reinterpret_cast<const float4*>(a + c0);
-    const float4* bp = reinterpret_cast<const float4*>(b + c0);
-    const int64_t CV = C / 4;
+__device__ __forceinline__ void slab_colsum2(const float* __restrict__ a, const float* __restrict__ b, int RB, int C, int c,
+                                             int rl, double (*sh)[FIN_LANES][5], double& sa, double& sb) {
+  double x = 0.0, y = 0.0;
+  if (c < C) {
+    double x1 = 0.0, x2 = 0.0, x3 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
     int r = rl;
     for (; r + 3 * FIN_LANES < RB; r += 4 * FIN_LANES) {
-      const float4 a0 = ap[(int64_t)r * CV], a1 = ap[(int64_t)(r + FIN_LANES) * CV];
-      const float4 a2 = ap[(int64_t)(r + 2 * FIN_LANES) * CV], a3 = ap[(int64_t)(r + 3 * FIN_LANES) * CV];
-      const float4 b0 = bp[(int64_t)r * CV], b1 = bp[(int64_t)(r + FIN_LANES) * CV];
-      const float4 b2 = bp[(int64_t)(r + 2 * FIN_LANES) * CV], b3 = bp[(int64_t)(r + 3 * FIN_LANES) * CV];
-      acc4(x, a0); acc4(x1, a1); acc4(x2, a2); acc4(x3, a3);
-      acc4(y, b0); acc4(y1, b1); acc4(y2, b2); acc4(y3, b3);
+      const float a0 = a[(int64_t)r * C + c], a1 = a[(int64_t)(r + FIN_LANES) * C + c];
+      const float a2 = a[(int64_t)(r + 2 * FIN_LANES) * C + c], a3 = a[(int64_t)(r + 3 * FIN_LANES) * C + c];
+      const float b0 = b[(int64_t)r * C + c], b1 = b[(int64_t)(r + FIN_LANES) * C + c];
+      const float b2 = b[(int64_t)(r + 2 * FIN_LANES) * C + c], b3 = b[(int64_t)(r + 3 * FIN_LANES) * C + c];
+      x += (double)a0; x1 += (double)a1; x2 += (double)a2; x3 += (double)a3;
+      y += (double)b0; y1 += (double)b1; y2 += (double)b2; y3 += (double)b3;
     }
     for (; r < RB; r += FIN_LANES) {
-      acc4(x, ap[(int64_t)r * CV]);
-      acc4(y, bp[(int64_t)r * CV]);
+      x += (double)a[(int64_t)r * C + c];
+      y += (double)b[(int64_t)r * C + c];
     }
-    x = tree4(x, x1, x2, x3);
-    y = tree4(y, y1, y2, y3);
+    x = (x + x1) + (x2 + x3);
+    y = (y + y1) + (y2 + y3);
   }
-  const int cl = 4 * cq;
-  sh[0][rl][cl] = x.x; sh[0][rl][cl + 1] = x.y; sh[0][rl][cl + 2] = x.z; sh[0][rl][cl + 3] = x.w;
-  sh[1][rl][cl] = y.x; sh[1][rl][cl + 1] = y.y; sh[1][rl][cl + 2] = y.z; sh[1][rl][cl + 3] = y.w;
+  const int cl = threadIdx.x & 3;
+  sh[0][rl][cl] = x;
+  sh[1][rl][cl] = y;
   __syncthreads();
-  double u[4] = {0.0, 0.0, 0.0, 0.0}, v[4] = {0.0, 0.0, 0.0, 0.0};
+  double u = 0.0, v = 0.0;
   if (rl < 16) {  // lane rl sums lanes 16 rl .. 16 rl + 15, in order
-    for (int k = 0; k < 16; ++k)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        u[e] += sh[0][16 * rl + k][cl + e];
-        v[e] += sh[1][16 * rl + k][cl + e];
-      }
+    for (int k = 0; k < 16; ++k) {
+      u += sh[0][16 * rl + k][cl];
+      v += sh[1][16 * rl + k][cl];
+    }
   }
   __syncthreads();
   if (rl < 16) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      sh[0][rl][cl + e] = u[e];
-      sh[1][rl][cl + e] = v[e];
-    }
+    sh[0][rl][cl] = u;
+    sh[1][rl][cl] = v;
   }
   __syncthreads();
-  sa = zero;
-  sb = zero;
+  sa = 0.0;
+  sb = 0.0;
   if (rl == 0) {
     for (int k = 0; k < 16; ++k) {
-      sa.x += sh[0][k][cl]; sa.y += sh[0][k][cl + 1]; sa.z += sh[0][k][cl + 2]; sa.w += sh[0][k][cl + 3];
-      sb.x += sh[1][k][cl]; sb.y += sh[1][k][cl + 1]; sb.z += sh[1][k][cl + 2]; sb.w += sh[1][k][cl + 3];
+      sa += sh[0][k][cl];
+      sb += sh[1][k][cl];
     }
   }
 }
 
-__device__ __forceinline__ void bn_finalize_one(double s, double q, int c, int64_t M, const float* __restrict__ gamma,
-                                                const float* __restrict__ beta, float eps, float momentum,
-                                                float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                float* __restrict__ scale, float* __restrict__ shift) {
+__global__ __launch_bounds__(4 * FIN_LANES) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int RB,
+                                                           int64_t M, int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                           float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double sh[2][FIN_LANES][5];
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3), rl = threadIdx.x >> 2;
+  double s, q;
+  slab_colsum2(psum, psq, RB, C, c, rl, sh, s, q);
+  if (rl != 0 || c >= C) return;
   const double mean = s / (double)M;
   double var = q / (double)M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -166,24 +151,6 @@ __device__ __forceinline__ void bn_finalize_one(double s, double q, int c, int64
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
-}
-
-__global__ __launch_bounds__(4 * FIN_LANES) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int RB,
-                                                           int64_t M, int C, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps, float momentum,
-                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                           float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double sh[2][FIN_LANES][FIN_CH + 1];
-  const int cq = threadIdx.x & 3, rl = threadIdx.x >> 2;
-  const int c = blockIdx.x * FIN_CH + 4 * cq;
-  dbl4 s, q;
-  slab_colsum2(psum, psq, RB, C, c, rl, cq, sh, s, q);
-  if (rl != 0 || c >= C) return;
-  bn_finalize_one(s.x, q.x, c, M, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
-  bn_finalize_one(s.y, q.y, c + 1, M, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
-  bn_finalize_one(s.z, q.z, c + 2, M, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
-  bn_finalize_one(s.w, q.w, c + 3, M, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
 }
 
 __global__ void bn_eval_params_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -331,24 +298,17 @@ __global__ __launch_bounds__(4 * FIN_LANES) void bn_bwd_finalize_kernel(const fl
                                                                int64_t M, int C, const float* __restrict__ gamma,
                                                                const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float beta_acc, float* __restrict__ coef) {
-  __shared__ double sh[2][FIN_LANES][FIN_CH + 1];
-  const int cq = threadIdx.x & 3, rl = threadIdx.x >> 2;
-  const int c0 = blockIdx.x * FIN_CH + 4 * cq;
-  dbl4 t1, t2;
-  slab_colsum2(p1, p2, RB, C, c0, rl, cq, sh, t1, t2);
-  if (rl != 0 || c0 >= C) return;
-  const double s1v[4] = {t1.x, t1.y, t1.z, t1.w}, s2v[4] = {t2.x, t2.y, t2.z, t2.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int c = c0 + e;
-    const double s1 = s1v[e], s2 = s2v[e];
-    if (dgamma != nullptr) dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)s2;
-    if (dbeta != nullptr) dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)s1;
-    const float a = gamma[c] * invstd[c];
-    coef[c] = a;
-    coef[C + c] = (float)(s1 / (double)M);
-    coef[2 * C + c] = (float)(s2 / (double)M);
-  }
+  __shared__ double sh[2][FIN_LANES][5];
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3), rl = threadIdx.x >> 2;
+  double s1, s2;
+  slab_colsum2(p1, p2, RB, C, c, rl, sh, s1, s2);
+  if (rl != 0 || c >= C) return;
+  if (dgamma != nullptr) dgamma[c] = (beta_acc != 0.f ? beta_acc * dgamma[c] : 0.f) + (float)s2;
+  if (dbeta != nullptr) dbeta[c] = (beta_acc != 0.f ? beta_acc * dbeta[c] : 0.f) + (float)s1;
+  const float a = gamma[c] * invstd[c];
+  coef[c] = a;
+  coef[C + c] = (float)(s1 / (double)M);
+  coef[2 * C + c] = (float)(s2 / (double)M);
 }
 
 template <int RELU, bool NT = false, int ES = 4>
@@ -517,7 +477,7 @@ extern "C" int bdv_bn_train_stats(const float* y, int64_t M, int C, const float*
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_partial_kernel, dim3(b.RB, b.CC), dim3(256), 0, s, y, psum, psq, M, C, b.CVB, b.RL, b.rows_per_block);
   BDV_LAUNCH_CHECK("bdv_bn_train_stats(partial)");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(4 * FIN_LANES), 0, s, (const float*)psum, (const float*)psq, b.RB,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(4 * FIN_LANES), 0, s, (const float*)psum, (const float*)psq, b.RB,
                      M, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
   BDV_LAUNCH_CHECK("bdv_bn_train_stats(finalize)");
   return BDV_OK;
@@ -529,7 +489,7 @@ extern "C" int bdv_bn_train_finalize(const float* partial, int rows, int64_t M, 
   BDV_REQUIRE(partial && gamma && beta && save_mean && save_invstd && scale && shift, "bdv_bn_train_finalize: null pointer");
   BDV_REQUIRE(rows > 0 && M > 0 && C > 0 && C % 4 == 0, "bdv_bn_train_finalize: bad shape");
   BDV_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bdv_bn_train_finalize: running stats must come in pairs");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(4 * FIN_LANES), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(4 * FIN_LANES), 0, (hipStream_t)stream, partial,
                      partial + (size_t)rows * C, rows, M, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
                      save_invstd, scale, shift);
   BDV_LAUNCH_CHECK("bdv_bn_train_finalize");
@@ -620,7 +580,7 @@ extern "C" int bdv_bn_backward(const void* dout, const uint32_t* relu_mask, cons
 #undef BDV_BWD_PARTIAL
     BDV_LAUNCH_CHECK("bdv_bn_backward(partial)");
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(4 * FIN_LANES), 0, s, q1, q2, rows, M, C, gamma, save_invstd, dgamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(4 * FIN_LANES), 0, s, q1, q2, rows, M, C, gamma, save_invstd, dgamma,
                      dbeta, beta_acc, coef);
   BDV_LAUNCH_CHECK("bdv_bn_backward(finalize)");
   BDV_REQUIRE(act_dtype == BDV_ACT_F32 || C % 8 == 0, "bdv_bn_backward: bf16 tensors need C %% 8 == 0 (16-byte units)");
@@ -675,7 +635,7 @@ extern "C" int bdv_bn_backward_maxpool(const void* dpool, const uint8_t* pool_id
                      (const float4*)y, (const float4*)save_mean, (const float4*)save_invstd, (const float4*)nullptr,
                      (float4*)nullptr, p1, p2, N, H, W, CV, Ho, Wo));
   BDV_LAUNCH_CHECK("bdv_bn_backward_maxpool(partial)");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(4 * FIN_LANES), 0, s, (const float*)p1, (const float*)p2, gx * gy, M, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(4 * FIN_LANES), 0, s, (const float*)p1, (const float*)p2, gx * gy, M, C,
                      gamma, save_invstd, dgamma, dbeta, beta_acc, coef);
   BDV_LAUNCH_CHECK("bdv_bn_backward_maxpool(finalize)");
   BDV_ACT_SWITCH(dpool_dtype, ES, hipLaunchKernelGGL((bn_bwd_pool_kernel<true, ES>), grid, blk, 0, s, dpool, (const uchar4*)pool_idx, relu_mask,

@@ -40,7 +40,7 @@ PEAK_BF16_MFMA = 2516.6e12         # v_mfma_f32_32x32x16_bf16: 32 cycles per 32x
 # An fp32 product formed from three bf16 pieces per operand costs six bf16 MFMA products: the MFMA-bound rate of the
 # default conv kernels in fp32-equivalent FLOP (2*M*N*K per GEMM) is the bf16 dense peak / 6.
 PEAK_BF16X3 = PEAK_BF16_MFMA / 6.0
-PROFILE_ROUND = 'r02'
+PROFILE_ROUND = 'r03'
 
 
 def model_cfg(depth, num_classes, head, loss, dropout):
@@ -432,7 +432,11 @@ def main():
             dom = max(conv_rows, key=lambda k: conv_rows[k]['ms'])
             timer.only = dom
     sync()
+    # one event per step boundary on the compute stream (a record costs about a microsecond): per-step times for the median the
+    # survey's measurement definition asks for; `value` stays total clips / wall time of the K steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     sampled = 0
     for i in range(args.steps):
         # one timed step in 16 (the 9th, 25th, ...; the middle one of a short run) carries the event pairs, with the side streams
@@ -442,9 +446,11 @@ def main():
         Fn.set_side_stream_enabled(side_default and not sample)
         sampled += int(sample)
         out = engine.step(batch, loss_fn)
+        marks[i + 1].record()
     Fn.set_side_stream_enabled(side_default)
     sync()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     timer.enabled = False
     loss_val = float(out['loss_cls'].item())
     if use_dist:
@@ -480,7 +486,12 @@ def main():
                                       'fp32 tensors and results; conv products on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)'),
                        'conv_arith': args.arith,
                        'clips_per_gpu': args.batch, 'global_batch': args.batch * world,
-                       'final_loss': round(loss_val, 5)},
+                       'final_loss': round(loss_val, 5),
+                       # device time between step boundaries (HIP events): the median is insensitive to the one step in 16 that
+                       # carries the per-kernel event pairs and runs with one stream
+                       'ms_per_step_median': round(step_ms[len(step_ms) // 2], 3), 'ms_per_step_min': round(step_ms[0], 3),
+                       'ms_per_step_max': round(step_ms[-1], 3),
+                       'clips_per_s_at_median': round(args.batch * world * 1000.0 / step_ms[len(step_ms) // 2], 2)},
         }
         res['config'].update(dist_record(reducer, world))
         if reducer is not None:
