@@ -27,7 +27,7 @@ print('# mfma_util = SQ_INSTS_MFMA x (32 | 64) / (GRBM_GUI_ACTIVE / 8 x 1024); v
 cols = None
 for da, db in zip(ka, kb):              # the two passes launch the same kernels in the same order
     (name, va), (name_b, vb) = a[da], b[db]
-    if name.split(':')[0] != name_b.split(':')[0]:
+    if name.split(':')[0] != name_b.split(':')[0] or not (name.startswith('conv_') or name.startswith('wgrad_reduce')):
         continue
     v = dict(va)
     v.update(vb)

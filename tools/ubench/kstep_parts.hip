@@ -10,7 +10,9 @@
 //   6  as 5, but the B planes go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPRs, no ds_write_b128): issued first in
 //      the step, a counted s_waitcnt vmcnt(2) (the two activation loads stay in flight) and a raw s_barrier
 //   7  as 6 with __syncthreads() (the compiler then drains every load at the barrier)
-// Prints cycles per K-step (s_memtime over the loop, median over workgroups), the in-kernel clock and TFLOP/s-equivalent.
+// Prints cycles per K-step (s_memtime over the loop until ALL waves of the workgroup are done, median over workgroups), the in-kernel
+// clock and TFLOP/s-equivalent.  (Levels 0 and 1 have no barrier in the loop: the compiler hoists the fragment reads of level 1 out
+// of it, and the two waves of a SIMD are served oldest first -- wave 0 alone sees 1537 cycles per K-step, its partner runs after it.)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(512) void kstep_kernel(const float* __restrict__ A,
     gload(kt + 2);
     sync();
   }
+  __syncthreads();      // the matrix pipe serves the older wave of a SIMD first: without this, wave 0's clock would only show ITS half
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
   if (tid == 0) {
     stamps[2 * blockIdx.x] = t1 - t0;
