@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # is then the caller's business
 _OVERRIDE = os.environ.get('BDVCIL_LIB_PATH')
 LIB_PATH = _OVERRIDE or os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _lib = None
 

@@ -1938,6 +1938,8 @@ __device__ __forceinline__ int pl_frag_off(int row0, int s, int lane) {
 
 // NP = 3: the six piece products (fp32-level result).  NP = 1: only the leading bf16 piece of each operand, one MFMA product
 // per step -- the reduced-precision arithmetic of BASELINE config 5 (bf16 operands, fp32 accumulate), see bdv_conv_fprop_pl.
+// NP = 2: the two leading pieces of each operand (16 significand bits) and the three products hi*hi + hi*mid + mid*hi: dropped
+// terms <= 2^-16 (mid*mid) + 2 * 2^-17 (the operands' remainders) relative per product -- between TF32 (2^-11) and fp32.
 template <int BM, int BN, int WM, int WN, int NP = 3>
 __device__ __forceinline__ void mma_stage_pl(const unsigned char* __restrict__ As, const unsigned char* __restrict__ Bs,
                                              f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const int (&fa)[2], const int (&fb)[2]) {
@@ -1961,6 +1963,8 @@ __device__ __forceinline__ void mma_stage_pl(const unsigned char* __restrict__ A
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+        }
+        if constexpr (NP >= 2) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
         }
@@ -1980,7 +1984,7 @@ __device__ __forceinline__ void pl_split_store_at(unsigned char* __restrict__ q,
   split3_pairs(v, hi, mid, lo);
   *reinterpret_cast<u32x2_t*>(q) = hi;
   *reinterpret_cast<u32x2_t*>(q + plane_bytes) = mid;
-  *reinterpret_cast<u32x2_t*>(q + 2 * plane_bytes) = lo;
+  if constexpr (NP == 3) *reinterpret_cast<u32x2_t*>(q + 2 * plane_bytes) = lo;
 }
 
 // ---- weights -> bf16 planes ------------------------------------------------------------------
@@ -2419,7 +2423,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM == 64 ? 4 : pl_waves_per_simd(WM *
     store_partial<TM, TN, NTHR>(slab, it.pslot, acc, tid);
     return;
   }
-  constexpr bool EPI_PIPE = TM * TN <= 4 && NP == 3 && BM != 64;   // 64 accumulator registers, two waves per SIMD
+  constexpr bool EPI_PIPE = TM * TN <= 4 && NP >= 2 && BM != 64;   // 64 accumulator registers, two waves per SIMD
   dgrad_epilogue<BM, BN, WM, WN, true, ES, EPI_PIPE>(acc, smem, tid, dx, add_src, add_mask, g, mt, nt, Mc, stat, [&](int mrow) {
     if (st == 1) return mrow;
     const int n = mrow / HcWc;
@@ -2453,7 +2457,7 @@ __device__ __forceinline__ void pl_store_rows(unsigned char* __restrict__ base, 
   unsigned char* q = base + krow * PITCH + 8 * c4;
   *reinterpret_cast<u32x2_t*>(q) = hi;
   *reinterpret_cast<u32x2_t*>(q + PLANE) = mid;
-  *reinterpret_cast<u32x2_t*>(q + 2 * PLANE) = lo;
+  if constexpr (NP == 3) *reinterpret_cast<u32x2_t*>(q + 2 * PLANE) = lo;
 }
 
 // 8 k-values (pixels 16 s + 8 h .. + 7) of channel `cb + (lane & 31)` of plane image `p`
@@ -2678,6 +2682,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_wgrad_pl_kernel(const vo
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][j], acc[i][j], 0, 0, 0);
+          }
+          if constexpr (NP >= 2) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0][j], acc[i][j], 0, 0, 0);
           }
@@ -2965,6 +2971,13 @@ int pl_pick(bool dgrad, int ncols, int nk, int taps, int stride, int pieces = 3,
     if (np1_small && small_ok && ncols % 128 == 0) return 4;
     return ncols % 256 == 0 ? 0 : ncols % 128 == 0 ? 1 : ncols % 64 == 0 ? 3 : -1;
   }
+  if (pieces == 2) {
+    // Two pieces per operand, three products: only the plane kernels have the form, so the sites the three-piece rules leave to the
+    // conv_*_x3 kernels take the 128x128 four-wave tile (two workgroups per CU, like them) here.
+    if (forced >= 0 && forced < kNumPlCfg && ncols % kPlCfg[forced].BN == 0 && (forced != 4 || (dgrad && stride == 1))) return forced;
+    const int c = pl_pick(dgrad, ncols, nk, taps, stride, 3, shifted);
+    return c >= 0 ? c : ncols % 128 == 0 ? 5 : ncols % 64 == 0 ? 3 : -1;
+  }
   if (forced == kNumPlCfg) return -1;  // "none": the kernels of the other family everywhere
   if (forced >= 0 && ncols % kPlCfg[forced].BN == 0 && (forced != 4 || (dgrad && stride == 1))) return forced;   // (three pieces: the 64x128 tile exists for dgrad only)
   if (ncols % 64 != 0) return -1;
@@ -3172,7 +3185,7 @@ extern "C" size_t bdv_conv_workspace_bytes(const bdv_conv_geom* gg, int kind) {
   }
   size_t need = p.wk.split > 1 ? (size_t)p.wk.rem_tiles * p.wk.split * p.seg_bytes : 0;
   // the P kernels (bdv_conv_fprop_pl / bdv_conv_dgrad_pl) plan their own K-split
-  for (int pieces = 1; pieces <= 3; pieces += 2) {
+  for (int pieces = 1; pieces <= 3; ++pieces) {
     if (kind == 0 && (pl_fprop_ok(gg, pieces) || (pieces == 3 && pl_fprop_cfg_pre(gg) >= 0))) {
       const PlPlan q = plan_pl(pl_fprop_ok(gg, pieces) ? pl_fprop_cfg(gg, pieces) : pl_fprop_cfg_pre(gg), g.M, g.Cout, g.Ktot / BK, kMaxSplitWorkspace, true);
       const size_t n2 = q.wk.split > 1 ? (size_t)q.wk.rem_tiles * q.wk.split * q.seg_bytes : 0;
@@ -3379,15 +3392,17 @@ extern "C" int bdv_conv_debug_force_tile(int cfg) {
 
 // Name of the main kernel a call will launch (as rocprofv3 prints it, without the anonymous namespace): for profiles and
 // bench.py's per-kernel accounting.  kind 0 = fprop, 1 = dgrad, 2 = wgrad; arith 0 = fp32 MFMA entry points, 1 = the default
-// bf16-piece entry points (bdv_conv_fprop_pl / bdv_conv_dgrad_pl / bdv_conv_wgrad_partial_pl), 2 = the same with pieces = 1.
+// bf16-piece entry points (bdv_conv_fprop_pl / bdv_conv_dgrad_pl / bdv_conv_wgrad_partial_pl), 2 = the same with pieces = 1,
+// 3 = with pieces = 2.
 extern "C" int bdv_conv_kernel_name(const bdv_conv_geom* gg, int kind, int arith, char* out, size_t n) {
   if (int e = check_geom(gg, "bdv_conv_kernel_name")) return e;
   BDV_REQUIRE(out && n > 0 && kind >= 0 && kind <= 2, "bdv_conv_kernel_name: bad argument");
   const bool c4 = gg->Cin % BK != 0;
+  const int pieces = arith == 2 ? 1 : arith == 3 ? 2 : 3;
   if (kind == 0) {
-    const int cfg = arith ? pl_fprop_cfg(gg, arith == 2 ? 1 : 3) : -1;
+    const int cfg = arith ? pl_fprop_cfg(gg, pieces) : -1;
     if (cfg >= 0) {
-      snprintf(out, n, "conv_fprop_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, pl_cfg_wm(cfg), pl_cfg_wn(cfg), kPlCfg[cfg].nbuf, arith == 2 ? 1 : 3);
+      snprintf(out, n, "conv_fprop_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, pl_cfg_wm(cfg), pl_cfg_wn(cfg), kPlCfg[cfg].nbuf, pieces);
     } else if (c4) {
       snprintf(out, n, "conv_fprop_c4_%skernel<128, %d, 2, 2>", arith && c4_x3_enabled() ? "x3_" : "", gg->Cout % 128 == 0 ? 128 : 64);
     } else if (gg->Cout % 128 == 0 && arith) {
@@ -3396,9 +3411,9 @@ extern "C" int bdv_conv_kernel_name(const bdv_conv_geom* gg, int kind, int arith
       snprintf(out, n, "conv_fprop_kernel<128, %d, 2, 2>", gg->Cout % 128 == 0 ? 128 : 64);
     }
   } else if (kind == 1) {
-    const int cfg = arith ? pl_dgrad_cfg(gg, arith == 2 ? 1 : 3) : -1;
+    const int cfg = arith ? pl_dgrad_cfg(gg, pieces) : -1;
     if (cfg >= 0) {
-      snprintf(out, n, "conv_dgrad_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, pl_cfg_wm(cfg), pl_cfg_wn(cfg), kPlCfg[cfg].nbuf, arith == 2 ? 1 : 3);
+      snprintf(out, n, "conv_dgrad_pl_kernel<%d, %d, %d, %d, %d, %d>", kPlCfg[cfg].BM, kPlCfg[cfg].BN, pl_cfg_wm(cfg), pl_cfg_wn(cfg), kPlCfg[cfg].nbuf, pieces);
     } else if (gg->Cin % 128 == 0 && arith) {
       snprintf(out, n, "conv_dgrad_x3_kernel<128, 128, 2, 2, %s>", r1_planes_enabled() ? "true" : "false");
     } else {
@@ -3418,8 +3433,8 @@ extern "C" int bdv_conv_kernel_name(const bdv_conv_geom* gg, int kind, int arith
 
 extern "C" int bdv_conv_uses_planes(const bdv_conv_geom* gg, int kind, int pieces) {
   if (check_geom(gg, "bdv_conv_uses_planes")) return 0;
-  if (kind == 0) return pl_fprop_ok(gg, pieces) || (pieces == 3 && r1_planes_enabled() && gg->Cin % BK == 0 && gg->Cout % 128 == 0) ? 1 : 0;
-  if (kind == 1) return pl_dgrad_ok(gg, pieces) || (pieces == 3 && r1_planes_enabled() && gg->Cout % BK == 0 && gg->Cin % 128 == 0) ? 1 : 0;
+  if (kind == 0) return pl_fprop_ok(gg, pieces) || (pieces >= 2 && r1_planes_enabled() && gg->Cin % BK == 0 && gg->Cout % 128 == 0) ? 1 : 0;
+  if (kind == 1) return pl_dgrad_ok(gg, pieces) || (pieces >= 2 && r1_planes_enabled() && gg->Cout % BK == 0 && gg->Cin % 128 == 0) ? 1 : 0;
   return 0;
 }
 
@@ -3469,7 +3484,7 @@ extern "C" int bdv_conv_fprop_pl(const void* x, const float* w, const void* plan
                                  float* bn_partial, const bdv_conv_affine* affine, void* workspace, size_t workspace_bytes,
                                  int pieces, const float* pre_scale, const float* pre_shift, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_fprop_pl")) return e;
-  BDV_REQUIRE(pieces == 3 || pieces == 1, "bdv_conv_fprop_pl: pieces = %d (3 or 1)", pieces);
+  BDV_REQUIRE(pieces >= 1 && pieces <= 3, "bdv_conv_fprop_pl: pieces = %d (3, 2 or 1)", pieces);
   const bool pre = pre_scale != nullptr;
   const bool h16 = gg->act_dtype == BDV_ACT_BF16;
   BDV_REQUIRE_ACT(gg->act_dtype, "bdv_conv_fprop_pl");
@@ -3524,6 +3539,9 @@ extern "C" int bdv_conv_fprop_pl(const void* x, const float* w, const void* plan
     else if (pieces == 1)                                                                                                             \
       hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_, 1>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y, g,    \
                          p.NT, p.wk, slab, epi);                                                                                      \
+    else if (pieces == 2)                                                                                                             \
+      hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_, 2>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y, g,    \
+                         p.NT, p.wk, slab, epi);                                                                                      \
     else                                                                                                                              \
       hipLaunchKernelGGL((conv_fprop_pl_kernel<BM_, BN_, WM_, WN_, NB_, 3>), dim3(blocks), dim3(64 * WM_ * WN_), 0, s, x, wp, y, g,    \
                          p.NT, p.wk, slab, epi);                                                                                      \
@@ -3547,7 +3565,7 @@ extern "C" int bdv_conv_dgrad_pl(const void* dy, const float* w, const void* pla
                                  const uint32_t* add_mask_src, const bdv_conv_geom* gg, const bdv_bn_stat_fuse* bn_stat,
                                  void* workspace, size_t workspace_bytes, int pieces, void* stream) {
   if (int e = check_geom(gg, "bdv_conv_dgrad_pl")) return e;
-  BDV_REQUIRE(pieces == 3 || pieces == 1, "bdv_conv_dgrad_pl: pieces = %d (3 or 1)", pieces);
+  BDV_REQUIRE(pieces >= 1 && pieces <= 3, "bdv_conv_dgrad_pl: pieces = %d (3, 2 or 1)", pieces);
   const bool h16 = gg->act_dtype == BDV_ACT_BF16;
   BDV_REQUIRE_ACT(gg->act_dtype, "bdv_conv_dgrad_pl");
   if (h16)
@@ -3605,6 +3623,9 @@ extern "C" int bdv_conv_dgrad_pl(const void* dy, const float* w, const void* pla
                          add_mask_src, g, p.NT, p.wk, slab, stat);                                                                     \
     else if (pieces == 1)                                                                                                              \
       hipLaunchKernelGGL((conv_dgrad_pl_kernel<BM_, BN_, WM_, WN_, NB_, 1>), grid, dim3(64 * WM_ * WN_), 0, s, dy, dp, dx, add_src,     \
+                         add_mask_src, g, p.NT, p.wk, slab, stat);                                                                     \
+    else if (pieces == 2)                                                                                                              \
+      hipLaunchKernelGGL((conv_dgrad_pl_kernel<BM_, BN_, WM_, WN_, NB_, 2>), grid, dim3(64 * WM_ * WN_), 0, s, dy, dp, dx, add_src,     \
                          add_mask_src, g, p.NT, p.wk, slab, stat);                                                                     \
     else                                                                                                                               \
       hipLaunchKernelGGL((conv_dgrad_pl_kernel<BM_, BN_, WM_, WN_, NB_, 3>), grid, dim3(64 * WM_ * WN_), 0, s, dy, dp, dx, add_src,     \
@@ -3732,7 +3753,7 @@ extern "C" int bdv_conv_wgrad_partial_pl(const void* dy, const void* x, const bd
   if (int e = check_geom(gg, "bdv_conv_wgrad_partial_pl")) return e;
   BDV_REQUIRE(pre_scale == nullptr || (pre_shift != nullptr && pl_wgrad_ok(gg) && gg->Cin % BK == 0 && gg->fold == 0),
               "bdv_conv_wgrad_partial_pl: a producer BatchNorm in the loader needs the plane kernel, Cin %% 32 == 0 and no temporal shift");
-  BDV_REQUIRE(pieces == 3 || pieces == 1, "bdv_conv_wgrad_partial_pl: pieces = %d (3 or 1)", pieces);
+  BDV_REQUIRE(pieces >= 1 && pieces <= 3, "bdv_conv_wgrad_partial_pl: pieces = %d (3, 2 or 1)", pieces);
   BDV_REQUIRE(dy && x && slab, "bdv_conv_wgrad_partial_pl: null pointer");
   BDV_REQUIRE(bdv_aligned16(dy) && bdv_aligned16(x) && bdv_aligned16(slab), "bdv_conv_wgrad_partial_pl: pointers must be 16-byte aligned");
   const bool h16 = gg->act_dtype == BDV_ACT_BF16;
@@ -3742,7 +3763,7 @@ extern "C" int bdv_conv_wgrad_partial_pl(const void* dy, const void* x, const bd
                 "bdv_conv_wgrad_partial_pl: bf16 activation storage needs pieces = 1 and the plane kernel (Cin %% 32 == 0; Cin=%d Cout=%d)", gg->Cin, gg->Cout);
   if (!pl_wgrad_ok(gg)) {
     int splits = 0;
-    return wgrad_partial("bdv_conv_wgrad_partial_pl", (const float*)dy, (const float*)x, gg, slab, slab_bytes, (hipStream_t)stream, &splits, pieces == 3);
+    return wgrad_partial("bdv_conv_wgrad_partial_pl", (const float*)dy, (const float*)x, gg, slab, slab_bytes, (hipStream_t)stream, &splits, pieces >= 2);
   }
   const WgradPlPlan p = plan_wgrad_pl(gg);
   const size_t need = (size_t)p.splits * gg->Cout * (gg->Rt > 1 ? gg->Rt : 1) * gg->R * gg->S * gg->Cin * sizeof(float);
@@ -3768,6 +3789,8 @@ extern "C" int bdv_conv_wgrad_partial_pl(const void* dy, const void* x, const bd
     else if (h16) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 1, MTAP_, (KW_ == 16 ? 32 : KW_), 2);                                 \
     else if (incr && pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 3, MTAP_, KW_, 4);                                     \
     else if (pieces == 3) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 3, MTAP_, KW_, 4);                                            \
+    else if (incr && pieces == 2) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 2, MTAP_, KW_, 4);                                     \
+    else if (pieces == 2) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 2, MTAP_, KW_, 4);                                            \
     else if (incr) BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, true, 1, MTAP_, KW_, 4);                                                    \
     else BDV_WGRAD_PL2(BM_, BN_, WM_, WN_, false, 1, MTAP_, KW_, 4);                                                             \
   } while (0)

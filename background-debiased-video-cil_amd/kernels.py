@@ -141,21 +141,23 @@ def _x3_default(name):
 FPROP_X3 = _x3_default('BDVCIL_FPROP_X3')
 
 
-PIECES = 3      # 3: fp32-level products from three bf16 pieces per operand; 1: single bf16 product (reduced precision, 'bf16x1')
+PIECES = 3      # 3: fp32-level products from three bf16 pieces per operand; 2: two pieces, three products ('bf16x2', 16 significand
+                # bits); 1: single bf16 product (reduced precision, 'bf16x1')
 
 
 def set_conv_arith(mode: str):
-    """'bf16x3' (default), 'f32mfma', or the reduced-precision modes of BASELINE config 5: 'bf16x1' (operands rounded to bf16, one
+    """'bf16x3' (default), 'f32mfma', 'bf16x2' (two bf16 pieces per operand, three MFMA products, 16 significand bits; the plane
+    kernels only, the other sites keep three pieces), or the reduced-precision modes of BASELINE config 5: 'bf16x1' (operands rounded to bf16, one
     MFMA product, fp32 accumulate, fp32 tensors) and 'bf16' (the same arithmetic with activations and their gradients STORED as
     bf16 between the stem's max-pool and the average pool; fp32 statistics, weights and weight gradients) for fprop, dgrad and
     wgrad at once; returns the previous (fprop, dgrad, wgrad) flags.
     Leaving 'bf16x1' needs another ``set_conv_arith`` call (the flags alone do not restore ``PIECES``)."""
     global FPROP_X3, DGRAD_X3, WGRAD_X3, PIECES, ACT_DTYPE
-    if mode not in ('bf16x3', 'f32mfma', 'bf16x1', 'bf16'):
-        raise ValueError(f"set_conv_arith: unknown mode {mode!r} ('bf16x3' | 'f32mfma' | 'bf16x1' | 'bf16')")
+    if mode not in ('bf16x3', 'f32mfma', 'bf16x2', 'bf16x1', 'bf16'):
+        raise ValueError(f"set_conv_arith: unknown mode {mode!r} ('bf16x3' | 'f32mfma' | 'bf16x2' | 'bf16x1' | 'bf16')")
     prev = (FPROP_X3, DGRAD_X3, WGRAD_X3)
     FPROP_X3 = DGRAD_X3 = WGRAD_X3 = (mode != 'f32mfma')
-    PIECES = 1 if mode in ('bf16x1', 'bf16') else 3
+    PIECES = 1 if mode in ('bf16x1', 'bf16') else 2 if mode == 'bf16x2' else 3
     # 'bf16': the bf16x1 arithmetic on bf16-STORED activations and gradients (BDV_ACT_BF16) from the stem's max-pool to the average
     # pool; the tensors the model creates from here on carry the type, every kernel follows the dtype of what it is given
     ACT_DTYPE = torch.bfloat16 if mode == 'bf16' else torch.float32
@@ -286,7 +288,7 @@ def conv_kernel_name(g: ConvGeom, kind: str, x3: Optional[bool] = None) -> str:
     k = {'fprop': 0, 'dgrad': 1, 'wgrad': 2}[kind]
     flag = (FPROP_X3, DGRAD_X3, WGRAD_X3)[k] if x3 is None else x3
     buf = ctypes.create_string_buffer(128)
-    check(lib().bdv_conv_kernel_name(ctypes.byref(g), k, (2 if PIECES == 1 else 1) if flag else 0, buf, 128), 'bdv_conv_kernel_name')
+    check(lib().bdv_conv_kernel_name(ctypes.byref(g), k, {3: 1, 1: 2, 2: 3}[PIECES] if flag else 0, buf, 128), 'bdv_conv_kernel_name')
     return buf.value.decode()
 
 

@@ -290,11 +290,14 @@ def main():
                          "I3D-ResNet50 fwd+bwd+SGD on 32x3x224x224 clips (default batch 16)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--arith', default='bf16x3', choices=['bf16x3', 'f32mfma', 'bf16x1', 'bf16'],
+    ap.add_argument('--arith', default='bf16x3', choices=['bf16x3', 'f32mfma', 'bf16x2', 'bf16x1', 'bf16'],
                     help="conv arithmetic: 'bf16x3' (default; fp32 products from three bf16 pieces per operand, six bf16 MFMA "
                          "products, fp32 accumulate), 'f32mfma' (v_mfma_f32_32x32x2_f32 kernels), or the REDUCED-PRECISION 'bf16x1' of BASELINE "
                          "config 5 (operands rounded to bf16, one MFMA product, fp32 accumulate and tensors; use with --batch 64; "
                          "reported with dtype bf16, never as the headline metric)")
+    ap.add_argument('--no-alt-arith', action='store_true',
+                    help="skip the second timed run of the same step in the 'bf16x2' arithmetic (two bf16 pieces per operand, three "
+                         "MFMA products; reported under `alt_arith`, never as `value`)")
     ap.add_argument('--selftest-cpu', action='store_true', help=argparse.SUPPRESS)   # launcher test: gloo ranks, no GPU
     args = ap.parse_args()
 
@@ -453,6 +456,47 @@ def main():
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     timer.enabled = False
     loss_val = float(out['loss_cls'].item())
+
+    # The same step once more in the 'bf16x2' arithmetic (16 significand bits per operand, three MFMA products instead of six):
+    # a second record beside the headline, which stays the fp32-level arithmetic.  Same model configuration, batch, warm-up and
+    # step count, same barrier + synchronize bracket, max over ranks.
+    alt = None
+    if args.arith == 'bf16x3' and not (cil or predict or i3d or args.no_alt_arith):
+        K.set_conv_arith('bf16x2')
+        torch.manual_seed(0)
+        model2 = bd.build_model(cfg).to(dev)
+        model2.train()
+        reducer2 = None
+        if use_dist:
+            bd.broadcast_parameters(model2)
+            reducer2 = bd.GradAllReducer(model2, bucket_cap_mb=float(os.environ.get('BDVCIL_BUCKET_MB', '25')))
+        engine2 = bd.TrainEngine(model2, bd.build_optimizer(model2, dict(type='SGD', constructor='CILTSMOptimizerConstructorImprovised',
+                                                                          paramwise_cfg=dict(fc_lr_scale_factor=5.0), lr=0.01, momentum=0.9,
+                                                                          weight_decay=1e-4)), grad_clip=None, reducer=reducer2)
+        for _ in range(args.warmup):
+            engine2.step(batch, None)
+        sync()
+        marks2 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        t1 = time.perf_counter()
+        marks2[0].record()
+        for i in range(args.steps):
+            out2 = engine2.step(batch, None)
+            marks2[i + 1].record()
+        sync()
+        dt2 = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([dt2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+        ms2 = sorted(marks2[i].elapsed_time(marks2[i + 1]) for i in range(args.steps))
+        alt = {'conv_arith': 'bf16x2', 'value': round(args.batch * world * args.steps / dt2, 2), 'unit': 'clips/s',
+               'ms_per_step': round(1000.0 * dt2 / args.steps, 3), 'ms_per_step_median': round(ms2[len(ms2) // 2], 3),
+               'final_loss': round(float(out2['loss_cls'].item()), 5),
+               'note': 'NOT the headline: the same workload, steps and warm-up with every conv operand cut to its two leading bf16 pieces '
+                       '(16 significand bits) and three v_mfma_f32_32x32x16_bf16 products (hi*hi + hi*mid + mid*hi), fp32 accumulate, fp32 '
+                       'tensors; dropped terms <= 2^-15 relative per product (fp32-level: 2^-24; TF32: 2^-11); plane kernels only, the stem '
+                       'keeps three pieces; parity bars of this arithmetic: tests/test_bf16x2_gpu.py'}
+        K.set_conv_arith(args.arith)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -465,19 +509,24 @@ def main():
         res = {
             'metric': (f'clips/sec fwd+bwd TSM-R50 8x224^2 bs{args.batch}/GPU, bf16 MFMA tiles (BASELINE config 5; not the headline metric)'
                        if args.arith in ('bf16x1', 'bf16') and args.depth == 50 and not (cil or predict or i3d) else
+                       f'clips/sec fwd+bwd TSM-R50 8x224^2 bs{args.batch}/GPU, two-piece bf16 conv products (not the headline metric)'
+                       if args.arith == 'bf16x2' and args.depth == 50 and not (cil or predict or i3d) else
                        'clips/sec fwd+bwd I3D-R50 32x224^2 bs16/GPU (BASELINE config 4; not the headline metric)' if i3d else
                        'clips/sec fwd+bwd TSM-R50 8x224^2 bs32/GPU' if args.depth == 50 else f'clips/sec fwd+bwd TSM-R{args.depth}')
                       + (' (CIL step: bg-mix front-end + KD teacher + LSCLoss)' if cil else '')
                       + (' (predict_step: eval forward + representations, no backward)' if predict else ''),
             'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000.0 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16' if args.arith in ('bf16x1', 'bf16') else 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'bf16' if args.arith in ('bf16x1', 'bf16') else 'bf16x2' if args.arith == 'bf16x2' else 'f32', 'data': 'synthetic',
             'config': {'workload': ('CIL task-1 step (uint8 bg-mix front-end, frozen teacher forward, 5 feature-KD MSE terms, clip 1.0): ' if cil else '')
                                    + (f'I3D-ResNet50 (ResNet3d, 3x1x1 inflation) fwd+bwd+SGD step, synthetic {args.batch}x3x32x224x224 clips per GPU, ' if i3d else
                                       f'TSM-ResNet{args.depth} ' + ('eval forward + clip representations (predict_step)' if predict else 'fwd+bwd+SGD step') + f', synthetic {args.batch}x8x3x224x224 clips per GPU, ')
                                    + f'{args.classes} classes, {"I3DHead" if i3d else args.head}+{args.loss}, dropout {args.dropout}, random-init weights; '
                                    + ('fp32 tensors, accumulators and results; conv products: fp32 via 3xbf16 split, 6 MFMA products, fp32 accumulate '
                                       '(dropped terms <= 2^-24 relative)' if args.arith == 'bf16x3' else
+                                      'fp32 tensors, accumulators and results; conv products from the TWO leading bf16 pieces of each operand (16 significand '
+                                      'bits), 3 MFMA products, fp32 accumulate (dropped terms <= 2^-15 relative; plane kernels only, the stem keeps three pieces)'
+                                      if args.arith == 'bf16x2' else
                                       'REDUCED PRECISION (BASELINE config 5): conv operands rounded to bf16, one bf16 MFMA product, fp32 accumulate, '
                                       'fp32 tensors' if args.arith == 'bf16x1' else
                                       'REDUCED PRECISION (BASELINE config 5): activations and their gradients STORED as bf16 between the stem max-pool and the '
@@ -494,6 +543,8 @@ def main():
                        'clips_per_s_at_median': round(args.batch * world * 1000.0 / step_ms[len(step_ms) // 2], 2)},
         }
         res['config'].update(dist_record(reducer, world))
+        if alt is not None:
+            res['alt_arith'] = alt
         if reducer is not None:
             res['n_gpus'] = reducer.describe()['ranks'] if world > 1 else world      # the communicator's count, not the launcher's
         ms = torch.cuda.memory_stats(dev)
@@ -510,14 +561,17 @@ def main():
             timed_steps = 1
             d = timer.summary()[dom]                      # the dominant kernel over the timed region
             bf16_pieces = '_x3_' in dom or '_pl_' in dom
-            peak = PEAK_BF16_MFMA if args.arith in ('bf16x1', 'bf16') and bf16_pieces else PEAK_BF16X3 if bf16_pieces else PEAK_F32_MFMA
+            two = args.arith == 'bf16x2' and dom.replace(' ', '').endswith(',2>')
+            peak = (PEAK_BF16_MFMA if args.arith in ('bf16x1', 'bf16') and bf16_pieces else PEAK_BF16_MFMA / 3 if two else
+                    PEAK_BF16X3 if bf16_pieces else PEAK_F32_MFMA)
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
             tot_ms = sum(v['ms'] for v in by.values())
             tot_fl = sum(v['flops'] for v in by.values())
             res['roofline'] = {
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak / 1e12, 1), 'unit': 'TFLOP/s',
                 'frac': round(achieved * 1e12 / peak, 4), 'traffic': pmc_traffic(dom),
-                'peak_note': ('fp32-equivalent FLOP (2*M*N*K) against the bf16 dense MFMA peak / 6: every fp32 product costs six '
+                'peak_note': ('FLOP (2*M*N*K) against the bf16 dense MFMA peak / 3: every product costs three v_mfma_f32_32x32x16_bf16 products' if two else
+                              'fp32-equivalent FLOP (2*M*N*K) against the bf16 dense MFMA peak / 6: every fp32 product costs six '
                               'v_mfma_f32_32x32x16_bf16 products' if bf16_pieces else 'v_mfma_f32_32x32x2_f32 dense peak'),
                 'frac_of_f32_mfma_peak': round(achieved * 1e12 / PEAK_F32_MFMA, 4),
                 'traffic_note': f'HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of '

@@ -152,7 +152,11 @@ int bdv_conv_dgrad_x3(const float* dy, const float* w, const float* w_t, float* 
  * fp16 tiles"; the reference's trainer is precision 32, libs/cil/cil.py:744-756, so there are no reference numerics for it):
  * each operand value is rounded to bf16 (only the hi plane is used), one v_mfma_f32_32x32x16_bf16 product per step, fp32
  * accumulate, fp32 tensors in HBM -- what torch.autocast(bfloat16) computes for a convolution, without the bf16 output rounding.
- * Error of a result: ~2^-9 relative per product, i.e. ~1e-3 .. 1e-2 of the output scale (tests/test_bf16x1_gpu.py). */
+ * Error of a result: ~2^-9 relative per product, i.e. ~1e-3 .. 1e-2 of the output scale (tests/test_bf16x1_gpu.py).
+ * pieces = 2 is the arithmetic in between ("bf16x2"): the hi and mid planes of each operand (16 significand bits) and the three
+ * products hi*hi + hi*mid + mid*hi per step, fp32 accumulate, fp32 tensors; dropped terms <= 2^-15 relative per product (five more
+ * bits than TF32, the conv arithmetic torch.backends.cudnn.allow_tf32 gives the reference on its GPUs); never the default, the
+ * plane kernels only (other shapes run the pieces = 3 kernels), no bf16 storage (tests/test_bf16x2_gpu.py). */
 size_t bdv_conv_weight_planes_bytes(const bdv_conv_geom* g);
 int bdv_conv_split_weights(const float* w, const bdv_conv_geom* g, void* planes_fprop, void* planes_dgrad, void* stream);
 /* Test / A-B hook, process-wide and not thread-safe: force the tile configuration of the two entry points below
@@ -163,7 +167,7 @@ int bdv_conv_debug_force_tile(int cfg);
  * runs a kernel that takes w (the caller then need not build the planes). */
 int bdv_conv_uses_planes(const bdv_conv_geom* g, int kind, int pieces);
 /* Name of the main kernel that a call with this geometry launches, as a profiler prints it (kind 0 fprop, 1 dgrad, 2 wgrad;
- * arith 0 = the fp32-MFMA entry points, 1 = the *_pl entry points, 2 = the same with pieces = 1).  For profiles and per-kernel
+ * arith 0 = the fp32-MFMA entry points, 1 = the *_pl entry points, 2 = the same with pieces = 1, 3 = with pieces = 2).  For profiles and per-kernel
  * accounting. */
 int bdv_conv_kernel_name(const bdv_conv_geom* g, int kind, int arith, char* out, size_t n);
 int bdv_conv_fprop_pl_stat_rows(const bdv_conv_geom* g, int pieces);

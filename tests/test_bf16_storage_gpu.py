@@ -312,6 +312,9 @@ def test_r50_gradient_fidelity_on_a_conditioned_problem(dev):
         no further from the fp32-level ones than 1.3 x what ``bf16x1`` on fp32 tensors already is;
     (3) a per-stage profile of the conv-weight gradients against the fp32-level ones, with floors a noise vector would miss by far
         (its cosine would be ~0): median cosine >= 0.6 in layer4 and >= 0.05 in every stage (measured 0.11-0.30 in conv1, depending on the summation order).
+        The ``bf16x2`` arithmetic (two bf16 pieces per operand, three products; tests/test_bf16x2_gpu.py) rides along: median cosine
+        >= 0.99 in every stage (measured 0.995 in the stem to 0.9993 in layer4, relative L2 0.04 - 0.10 -- three to four times the
+        distance between the two fp32-level arithmetics).
 
     What the measurement says about the absolute bar the round-2 review asked for (cosine >= 0.9 / relative L2 <= 0.3 for EVERY
     conv weight): it CANNOT be met by bf16 operands on this network, conditioned problem or not -- also not by ``bf16x1``, whose
@@ -360,7 +363,7 @@ def test_r50_gradient_fidelity_on_a_conditioned_problem(dev):
     assert worst_step <= 12e-2, worst_step
 
     losses, grads = {}, {}
-    for mode in ('bf16x3', 'f32mfma', 'bf16x1', 'bf16'):
+    for mode in ('bf16x3', 'f32mfma', 'bf16x2', 'bf16x1', 'bf16'):
         prev = K.set_conv_arith(mode)
         try:
             m = copy.deepcopy(base)
@@ -384,7 +387,7 @@ def test_r50_gradient_fidelity_on_a_conditioned_problem(dev):
     assert control >= 0.999, control                           # the instrument itself: two fp32-level arithmetics agree (measured 0.99974)
     stages = ['conv1', 'layer1', 'layer2', 'layer3', 'layer4']
     prof = {}
-    for mode in ('bf16x1', 'bf16'):
+    for mode in ('bf16x2', 'bf16x1', 'bf16'):
         for st in stages:
             names = [n for n in grads['bf16x3'] if n.startswith('backbone.' + st + '.') and (n.endswith('conv.weight') or n.endswith('net.weight'))]
             cs = sorted(cos(grads[mode][n], grads['bf16x3'][n]) for n in names)
@@ -393,7 +396,7 @@ def test_r50_gradient_fidelity_on_a_conditioned_problem(dev):
     _report(f'[config-5 gradient fidelity] loss curves fp32-level {curve[0]:.4f} -> {curve[-1]:.4f}, bf16 storage {curve16[0]:.4f} -> {curve16[-1]:.4f} '
             f'(worst step apart {worst_step:.3f}); control cosine fp32-MFMA vs default {control:.6f}; losses at the final weights {losses}; conv-weight gradients vs the fp32-level ones, per stage '
             f'(median cosine, min cosine, median relL2, max relL2): '
-            + '; '.join(f'{mode} {st} ({a:.2f}, {b:.2f}, {c:.2f}, {d:.2f})' for (mode, st), (a, b, c, d) in prof.items()))
+            + '; '.join(f'{mode} {st} ({a:.4f}, {b:.4f}, {c:.3f}, {d:.3f})' for (mode, st), (a, b, c, d) in prof.items()))
     assert all(torch.isfinite(g).all() for g in grads['bf16'].values())
     assert abs(losses['bf16'] - losses['bf16x3']) <= 1e-2 * abs(losses['bf16x3']), losses
     worst_ratio = 0.0
@@ -404,6 +407,7 @@ def test_r50_gradient_fidelity_on_a_conditioned_problem(dev):
             ratio = rel(grads['bf16'][n], g) / max(rel(grads['bf16x1'][n], g), 1e-3)
             worst_ratio = max(worst_ratio, ratio)
             assert ratio <= 1.3, (n, ratio)
+    assert all(prof[('bf16x2', st)][0] >= 0.99 for st in stages), {st: prof[('bf16x2', st)] for st in stages}   # two pieces: measured 0.995 - 0.9993
     for mode in ('bf16x1', 'bf16'):
         assert prof[(mode, 'layer4')][0] >= 0.6, (mode, prof[(mode, 'layer4')])
         # every stage stays positively correlated; the early stages' value moves with the summation order of the fp32-level
