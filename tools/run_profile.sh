@@ -19,6 +19,7 @@ python tools/pmc_traffic.py gpurun_out/$R/pmc_fetch gpurun_out/$R/pmc_write > gp
 timeout -k 10 300 python bench.py --workload cil --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/$R/bench_cil.json 2> gpurun_out/$R/bench_cil.err
 timeout -k 10 300 python bench.py --workload predict --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/$R/bench_predict.json 2> gpurun_out/$R/bench_predict.err
 timeout -k 10 300 python bench.py --workload i3d --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/$R/bench_i3d.json 2> gpurun_out/$R/bench_i3d.err
+timeout -k 10 300 python bench.py --arith bf16x2 --no-cpu-baseline > gpurun_out/$R/bench_bf16x2.json 2> gpurun_out/$R/bench_bf16x2.err
 timeout -k 10 300 python bench.py --arith bf16x1 --batch 64 --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/$R/bench_bf16x1.json 2> gpurun_out/$R/bench_bf16x1.err
 timeout -k 10 300 python bench.py --arith bf16 --batch 64 --no-cpu-baseline > gpurun_out/$R/bench_bf16.json 2> gpurun_out/$R/bench_bf16.err
 timeout -k 10 300 python bench.py --arith bf16 --workload cil --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/$R/bench_cil_bf16.json 2> gpurun_out/$R/bench_cil_bf16.err

@@ -16,6 +16,7 @@ from bdvcil_amd._lib import check, lib
 from tools.bench_conv import SHAPES, timeit  # noqa: E402
 
 N = int(os.environ.get('N', 256))
+K.set_conv_arith(os.environ.get('ARITH', 'bf16x3'))      # 'bf16x2': the r1 columns then still are three-piece kernels
 FUSED = os.environ.get('FUSED', '0') == '1'
 dev = torch.device('cuda:0')
 CFG = {0: '128x256', 1: '256x128', 2: '256x256', 3: '256x64', 4: '64x128', 5: '128x128'}
