@@ -8,14 +8,14 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint16, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BDVCIL_LIB_PATH: load another build of the library (A/B runs of two kernel versions in one gpurun call); the source-hash check
 # is then the caller's business
 _OVERRIDE = os.environ.get('BDVCIL_LIB_PATH')
 LIB_PATH = _OVERRIDE or os.path.join(_HERE, 'csrc', 'libbdvcil_hip.so')
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _lib = None
 
@@ -43,6 +43,15 @@ class BnStatFuse(Structure):
     _fields_ = [('y', c_void_p), ('relu_mask', c_void_p), ('mean', c_void_p), ('invstd', c_void_p), ('partial', c_void_p),
                 ('relu_scale', c_void_p), ('relu_shift', c_void_p)]
 
+class JpegInfo(Structure):
+    """Mirror of ``bdv_jpeg_info``."""
+    _fields_ = [('width', c_int32), ('height', c_int32), ('ncomp', c_int32), ('h', c_int32 * 3), ('v', c_int32 * 3),
+                ('blocks_w', c_int32 * 3), ('blocks_h', c_int32 * 3), ('down_w', c_int32 * 3), ('down_h', c_int32 * 3),
+                ('qt', (c_uint16 * 64) * 3), ('coef_offset', c_int64 * 3), ('coef_count', c_int64)]
+
+    def geometry_key(self):
+        """Everything ``bdv_jpeg_reconstruct_u8`` needs equal across a batch (all but the quantisation tables)."""
+        return (self.width, self.height, self.ncomp, tuple(self.h), tuple(self.v))
 
 
 # name -> (restype, argtypes)
@@ -95,6 +104,10 @@ SIGNATURES = {
     'bdv_avgpool_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_bgmix_normalize_u8': (c_int, [P, P, c_int, P, c_float, _F3, _F3, _F3, P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_bg_resize_crop_u8': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, P]),
+    'bdv_jpeg_parse': (c_int, [P, c_size_t, POINTER(JpegInfo)]),
+    'bdv_jpeg_entropy_decode': (c_int, [P, c_size_t, POINTER(JpegInfo), P]),
+    'bdv_jpeg_workspace_bytes': (c_size_t, [POINTER(JpegInfo), c_int]),
+    'bdv_jpeg_reconstruct_u8': (c_int, [P, P, POINTER(JpegInfo), c_int, P, c_size_t, P, P]),
     'bdv_crop_normalize_u8': (c_int, [P, P, c_int, c_int, c_int, _F3, _F3, P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_lsc_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_lsc_bwd': (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, c_int, P]),
@@ -130,7 +143,7 @@ class HipExtensionError(RuntimeError):
     pass
 
 
-HASHED_SOURCES = ('conv_mfma.hip', 'bn.hip', 'pool_frontend.hip', 'head_loss.hip', 'repr.hip', 'augment.hip', 'optim.hip',
+HASHED_SOURCES = ('conv_mfma.hip', 'bn.hip', 'pool_frontend.hip', 'head_loss.hip', 'repr.hip', 'augment.hip', 'optim.hip', 'jpeg.hip',
                   'api_common.cpp', 'common.h', 'Makefile', '../../include/bdvcil_hip.h')   # = HASHED in csrc/Makefile
 
 

@@ -13,7 +13,7 @@ void bdv_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* bdv_last_error(void) { return g_err; }
-extern "C" int bdv_abi_version(void) { return 28; }
+extern "C" int bdv_abi_version(void) { return 29; }
 extern "C" const char* bdv_source_hash(void) {
     return
 #include "src_hash.inc"

@@ -415,6 +415,35 @@ size_t bdv_randaug_workspace_bytes(int B, int T, int H, int W);
 int bdv_randaug_apply(const uint8_t* in, uint8_t* out, const int32_t* op_i, const double* op_d, int B, int T, int H,
                       int W, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- JPEG frame decode ----------------------------------------------
+ * The first stage of every pipeline of the configs: RawFrameDecode (configs/ucf101/bgmix_plus_randAug/
+ * bgmix_seed_1000_inc_10_stages_bgmix_plus_randAug.py:126, :144, :160; UPSTREAM mmaction2 RawFrameDecode ->
+ * mmcv.imfrombytes(channel_order='rgb') -> cv2.imdecode), i.e. libjpeg(-turbo) with its default ISLOW inverse DCT, fancy
+ * chroma upsampling and fixed-point YCbCr -> RGB: reproduced bit for bit (oracle/jpeg_oracle.py, pinned by Pillow's
+ * libjpeg-turbo).  Baseline / extended-sequential Huffman streams, 8-bit, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart
+ * intervals, interleaved or per-component scans; anything else returns BDV_EINVAL with the reason in bdv_last_error().
+ *   1. bdv_jpeg_parse          (host) header -> bdv_jpeg_info: sizes, sampling, block grids, the components' quantisation tables
+ *   2. bdv_jpeg_entropy_decode (host, thread-safe: call it from one thread per image) Huffman-decodes the stream into
+ *      QUANTISED coefficients, info->coef_count shorts: per component a raster of 64-short blocks in natural (row-major)
+ *      order over the MCU-padded block grid, component c at coef_offset[c]
+ *   3. bdv_jpeg_reconstruct_u8 (device) a batch of B images of ONE geometry (everything in `info` but the tables): coefs
+ *      (B, coef_count) int16 and qts (B, 3, 64) uint16 on the device -> rgb (B, height, width, 3) uint8; workspace =
+ *      bdv_jpeg_workspace_bytes(info, B) bytes (the component planes).  Two launches: dequantise + inverse DCT, then
+ *      upsample + colour conversion. */
+typedef struct {
+  int32_t width, height, ncomp;          /* ncomp: 1 (grey, written to all three output channels) or 3 (YCbCr) */
+  int32_t h[3], v[3];                    /* sampling factors */
+  int32_t blocks_w[3], blocks_h[3];      /* block grid of each component, padded to whole MCUs */
+  int32_t down_w[3], down_h[3];          /* real sample size of each component: ceil(width * h / hmax), ceil(height * v / vmax) */
+  uint16_t qt[3][64];                    /* each component's quantisation table, natural order */
+  int64_t coef_offset[3], coef_count;    /* in shorts, inside one image's coefficient buffer */
+} bdv_jpeg_info;
+int bdv_jpeg_parse(const unsigned char* data, size_t n, bdv_jpeg_info* info);
+int bdv_jpeg_entropy_decode(const unsigned char* data, size_t n, const bdv_jpeg_info* info, short* coefs);
+size_t bdv_jpeg_workspace_bytes(const bdv_jpeg_info* info, int B);
+int bdv_jpeg_reconstruct_u8(const short* coefs, const unsigned short* qts, const bdv_jpeg_info* info, int B, void* workspace,
+                            size_t workspace_bytes, unsigned char* rgb, void* stream);
+
 /* ---- optimizer: multi-tensor global-norm clip + SGD(momentum, wd) ---------------------------
  * torch.optim.SGD built at libs/cil/cil.py:467 with the groups of libs/models/cil_heads/tsm.py:273-303
  * and PL gradient_clip_val (cil.py:743).  Tables are device arrays, one entry per tensor. */
