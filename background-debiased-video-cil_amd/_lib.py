@@ -104,6 +104,7 @@ SIGNATURES = {
     'bdv_avgpool_bwd': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_bgmix_normalize_u8': (c_int, [P, P, c_int, P, c_float, _F3, _F3, _F3, P, P, c_int, c_int, c_int, c_int, P]),
     'bdv_bg_resize_crop_u8': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, P]),
+    'bdv_resize_linear_u8': (c_int, [P, c_int, c_int, c_int, P, c_int, P, P, c_int, c_int, P]),
     'bdv_jpeg_parse': (c_int, [P, c_size_t, POINTER(JpegInfo)]),
     'bdv_jpeg_entropy_decode': (c_int, [P, c_size_t, POINTER(JpegInfo), P]),
     'bdv_jpeg_workspace_bytes': (c_size_t, [POINTER(JpegInfo), c_int]),

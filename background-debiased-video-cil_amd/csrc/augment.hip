@@ -338,3 +338,121 @@ extern "C" int bdv_randaug_apply(const uint8_t* in, uint8_t* out, const int32_t*
   BDV_LAUNCH_CHECK("aug_apply_kernel");
   return BDV_OK;
 }
+
+// ---- Resize / MultiScaleCrop + Resize of the frame pipeline: OpenCV's INTER_LINEAR on 8-bit images -------------------------------
+// UPSTREAM mmaction2 Resize -> mmcv.imresize(interpolation='bilinear') -> cv2.resize(..., INTER_LINEAR) (configs/ucf101/
+// bgmix_plus_randAug/...py:127, :136; MultiScaleCrop's crop is a view, the Resize after it does the resampling).  cv2 is absent
+// from this image: the arithmetic below restates OpenCV's published fixed-point algorithm (imgproc/resize.cpp: coefficients in 11
+// fraction bits from float weights rounded half-to-even, a horizontal pass into 32-bit rows, a vertical pass
+// ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2 >> 2; the exact-2x shrink is the 2x2 box average cv::resize switches to)
+// -- PARITY UNPINNED, see oracle/resize_oracle.py.  The float / double operations are the same IEEE operations without contraction
+// (this file is built with -ffp-contract=off).
+namespace {
+
+struct ResizeAxis {
+  int s0, s1;     // source taps (already clamped into the box)
+  int a0, a1;     // 11-bit weights
+};
+
+__device__ __forceinline__ int sat_short(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+
+// x axis: a tap left of / beyond the last column collapses onto the edge with weight 1 (cv::resize clamps fx there)
+__device__ __forceinline__ ResizeAxis resize_axis_x(int d, double scale, int ssize) {
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= s;
+  if (s < 0) {
+    f = 0.f;
+    s = 0;
+  }
+  if (s >= ssize - 1) {
+    f = 0.f;
+    s = ssize - 1;
+  }
+  ResizeAxis r;
+  r.s0 = s;
+  r.s1 = s + 1 < ssize ? s + 1 : ssize - 1;
+  r.a0 = sat_short(__float2int_rn((1.f - f) * 2048.f));
+  r.a1 = sat_short(__float2int_rn(f * 2048.f));
+  return r;
+}
+
+// y axis: the weights keep the unclamped fraction, only the row indices are clipped (resizeGeneric_Invoker)
+__device__ __forceinline__ ResizeAxis resize_axis_y(int d, double scale, int ssize) {
+  float f = (float)((d + 0.5) * scale - 0.5);
+  const int s = (int)floorf(f);
+  f -= s;
+  ResizeAxis r;
+  r.s0 = s < 0 ? 0 : s >= ssize ? ssize - 1 : s;
+  r.s1 = s + 1 < 0 ? 0 : s + 1 >= ssize ? ssize - 1 : s + 1;
+  r.a0 = sat_short(__float2int_rn((1.f - f) * 2048.f));
+  r.a1 = sat_short(__float2int_rn(f * 2048.f));
+  return r;
+}
+
+// one thread per output pixel (3 channels); boxes: per group of T frames (x0, y0, w, h) inside the source frame, or NULL = the whole frame
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, const int32_t* __restrict__ boxes,
+                                                                uint8_t* __restrict__ dst, int N, int T, int Hs, int Ws, int Hd, int Wd) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per = (long long)Hd * Wd;
+  if (t >= per * N) return;
+  const int n = (int)(t / per);
+  const int pix = (int)(t - n * per);
+  const int dy = pix / Wd, dx = pix - dy * Wd;
+  int x0 = 0, y0 = 0, bw = Ws, bh = Hs;
+  if (boxes != nullptr) {
+    const int32_t* b = boxes + 4 * (n / T);
+    x0 = b[0];
+    y0 = b[1];
+    bw = b[2];
+    bh = b[3];
+  }
+  const uint8_t* base = src + ((size_t)n * Hs + y0) * Ws * 3 + (size_t)x0 * 3;
+  const size_t pitch = (size_t)Ws * 3;
+  uint8_t* o = dst + (size_t)t * 3;
+  if (bw == Wd && bh == Hd) {   // same size: cv::resize copies
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = base[dy * pitch + dx * 3 + c];
+    return;
+  }
+  if (bw == 2 * Wd && bh == 2 * Hd) {   // exact 2x shrink: INTER_LINEAR is replaced by the fast INTER_AREA (2x2 mean, rounded)
+    const uint8_t* p = base + (size_t)(2 * dy) * pitch + (size_t)(2 * dx) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (uint8_t)((p[c] + p[3 + c] + p[pitch + c] + p[pitch + 3 + c] + 2) >> 2);
+    return;
+  }
+  const double scale_x = 1.0 / ((double)Wd / bw), scale_y = 1.0 / ((double)Hd / bh);
+  const ResizeAxis ax = resize_axis_x(dx, scale_x, bw), ay = resize_axis_y(dy, scale_y, bh);
+  const uint8_t* r0 = base + (size_t)ay.s0 * pitch;
+  const uint8_t* r1 = base + (size_t)ay.s1 * pitch;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int h0 = r0[ax.s0 * 3 + c] * ax.a0 + r0[ax.s1 * 3 + c] * ax.a1;
+    const int h1 = r1[ax.s0 * 3 + c] * ax.a0 + r1[ax.s1 * 3 + c] * ax.a1;
+    const int v = (((ay.a0 * (h0 >> 4)) >> 16) + ((ay.a1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    o[c] = (uint8_t)v;
+  }
+}
+
+}  // namespace
+
+extern "C" int bdv_resize_linear_u8(const uint8_t* src, int N, int Hs, int Ws, const int32_t* boxes, int frames_per_box,
+                                    const int32_t* boxes_host, uint8_t* dst, int Hd, int Wd, void* stream) {
+  BDV_REQUIRE(src && dst && src != dst, "bdv_resize_linear_u8: null pointer / in-place");
+  BDV_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0, "bdv_resize_linear_u8: bad shape N=%d %dx%d -> %dx%d", N, Hs, Ws, Hd, Wd);
+  BDV_REQUIRE((boxes == nullptr) == (boxes_host == nullptr), "bdv_resize_linear_u8: the boxes are needed on the device AND on the host (they are validated here)");
+  if (boxes != nullptr) {
+    BDV_REQUIRE(frames_per_box > 0 && N % frames_per_box == 0, "bdv_resize_linear_u8: %d frames are not whole groups of %d", N, frames_per_box);
+    for (int i = 0; i < N / frames_per_box; ++i) {   // an out-of-range box would read outside the tensor: refuse on the host
+      const int32_t* b = boxes_host + 4 * i;
+      BDV_REQUIRE(b[2] > 0 && b[3] > 0 && b[0] >= 0 && b[1] >= 0 && b[0] + b[2] <= Ws && b[1] + b[3] <= Hs,
+                  "bdv_resize_linear_u8: box %d = (x %d, y %d, w %d, h %d) leaves the %d x %d frame", i, b[0], b[1], b[2], b[3], Ws, Hs);
+    }
+  }
+  const long long total = (long long)N * Hd * Wd;
+  BDV_REQUIRE(total / 256 < (1ll << 31), "bdv_resize_linear_u8: batch too large for one launch");
+  hipLaunchKernelGGL(resize_linear_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, boxes, dst, N,
+                     boxes ? frames_per_box : 1, Hs, Ws, Hd, Wd);
+  BDV_LAUNCH_CHECK("bdv_resize_linear_u8");
+  return BDV_OK;
+}

@@ -100,3 +100,130 @@ class JpegDecoder:
         flat = [s for c in clips for s in c]
         rgb = self.decode(flat)
         return rgb.view(len(clips), T, *rgb.shape[1:])
+
+
+def rescale_size(w: int, h: int, scale) -> Tuple[int, int]:
+    """UPSTREAM ``mmcv.rescale_size((w, h), scale)``: ``(-1, S)`` = short edge to S; sizes ``int(x * factor + 0.5)``."""
+    a, b = scale
+    long_edge, short_edge = (float('inf'), max(a, b)) if (a == -1 or b == -1) else (max(a, b), min(a, b))
+    factor = min(long_edge / max(h, w), short_edge / min(h, w))
+    return int(w * float(factor) + 0.5), int(h * float(factor) + 0.5)
+
+
+def sample_frames(total_frames: int, num_clips: int = 8, clip_len: int = 1, frame_interval: int = 1, test_mode: bool = False,
+                  start_index: int = 1) -> np.ndarray:
+    """UPSTREAM mmaction2 0.24 ``SampleFrames`` as the configs use it (``clip_len=1, frame_interval=1, num_clips=8``, no temporal
+    jitter, ``out_of_bound_opt='loop'``): 1-based numbers of the ``img_{:05}.jpg`` files; the train form draws from ``np.random``."""
+    ori = clip_len * frame_interval
+    if test_mode:
+        avg = (total_frames - ori + 1) / float(num_clips)
+        offsets = (np.arange(num_clips) * avg + avg / 2.0).astype(np.int64) if total_frames > ori - 1 else np.zeros((num_clips,), dtype=np.int64)
+    else:
+        avg = (total_frames - ori + 1) // num_clips
+        if avg > 0:
+            offsets = np.arange(num_clips) * avg + np.random.randint(avg, size=num_clips)
+        elif total_frames > max(num_clips, ori):
+            offsets = np.sort(np.random.randint(total_frames - ori + 1, size=num_clips))
+        elif avg == 0:
+            offsets = np.around(np.arange(num_clips) * ((total_frames - ori + 1.0) / num_clips))
+        else:
+            offsets = np.zeros((num_clips,), dtype=np.int64)
+    inds = (offsets[:, None] + np.arange(clip_len)[None, :] * frame_interval).reshape(-1)
+    return (np.mod(inds, total_frames).astype(np.int64) + start_index)
+
+
+class RawFrameClipLoader:
+    """The configs' four pipelines (configs/ucf101/bgmix_plus_randAug/bgmix_seed_1000_inc_10_stages_bgmix_plus_randAug.py:124-182) for a
+    whole batch, as the ``clip_loader`` of ``CILTaskLoop``: ``video_infos`` + phase -> the collated batch dict, frames never leaving HBM
+    after the coefficient upload.
+
+      train:                SampleFrames -> RawFrameDecode -> Resize(-1, 256) -> RandAugment -> MultiScaleCrop + Resize(224) -> Normalize,
+                            then the background mix of BackgroundMixDataset for the samples RandAugment skipped (comix_loader.py:105-145)
+      val / features_extraction: SampleFrames(test_mode) -> decode -> Resize(-1, 256) -> CenterCrop(224) -> Normalize
+      test:                 SampleFrames(test_mode) -> decode -> Resize(-1, 256) -> TenCrop(256) -> Normalize
+
+    Host work per batch: reading the files, the Huffman stage (thread pool) and the random draws -- per sample in the reference's order
+    (frame offsets from ``np.random``; RandAugment's own draws; crop size and offset from ``random``; background index and crop from
+    torch's generator), though a multi-worker DataLoader interleaves samples differently anyway.  ``bg_files``: JPEG backgrounds
+    (``back_ground_from_bg_dir``); without it a random frame of a random video of the batch's dataset serves (comix_loader.py:134-137
+    draws it from the whole dataset: pass ``bg_video_infos``)."""
+
+    def __init__(self, device='cuda', filename_tmpl: str = 'img_{:05}.jpg', num_segments: int = 8, start_index: int = 1,
+                 short_edge: int = 256, input_size: int = 224, randAug=None, randAug_prob: float = 0.75, alpha: float = 0.5,
+                 multi_scale_crop: dict = None, bg_files: Sequence[str] = None, bg_video_infos: Sequence[dict] = None,
+                 bg_resize: int = 256, test_crop=('TenCrop', 256), threads: int = 8):
+        from .augment import RandAugment
+        from .frontend import BackgroundCropFrontEnd, BackgroundMixFrontEnd, CropFrontEnd, MultiScaleCropResize, TrainClipFrontEnd
+        self.device = torch.device(device)
+        self.tmpl, self.T, self.start_index, self.short_edge = filename_tmpl, int(num_segments), int(start_index), int(short_edge)
+        self.decoder = JpegDecoder(self.device, threads)
+        msc = dict(input_size=input_size, scales=(1, 0.875, 0.75, 0.66), random_crop=False, max_wh_scale_gap=1, num_fixed_crops=13)
+        msc.update(multi_scale_crop or {})
+        self.train_front = TrainClipFrontEnd(randAug if randAug is not None else RandAugment(2, 10, randAug_prob), alpha=alpha,
+                                             with_randAug=True, crop_resize=MultiScaleCropResize(**msc))
+        self.bg_front = BackgroundCropFrontEnd(bg_resize, (input_size, input_size))
+        self.center = CropFrontEnd('CenterCrop', input_size)
+        self.test = CropFrontEnd(*test_crop)
+        self.bg_files, self.bg_video_infos = (list(bg_files) if bg_files else None), bg_video_infos
+        self.input_size = int(input_size)
+
+    # ---- host side ------------------------------------------------------------------------------------------------------------
+    def _read(self, path: str) -> bytes:
+        with open(path, 'rb') as f:
+            return f.read()
+
+    def _frames(self, video_infos: List[dict], test_mode: bool):
+        import os.path as osp
+        inds = [sample_frames(int(v['total_frames']), self.T, test_mode=test_mode, start_index=self.start_index) for v in video_infos]
+        paths = [osp.join(v['frame_dir'], self.tmpl.format(int(i))) for v, ii in zip(video_infos, inds) for i in ii]
+        streams = list(self.decoder.pool.map(self._read, paths))
+        clips = [streams[k * self.T:(k + 1) * self.T] for k in range(len(video_infos))]
+        return self.decoder.decode_clips(clips), np.stack(inds)
+
+    def _backgrounds(self, B: int, video_infos: List[dict]) -> torch.Tensor:
+        """One background per sample, cropped: (B, S, S, 3) fp32 pixel values (only the mixed samples' rows are read)."""
+        import os.path as osp
+        import random
+        paths = []
+        for _ in range(B):
+            if self.bg_files:
+                paths.append(self.bg_files[int(torch.randint(len(self.bg_files), (1,)).item())])
+            else:
+                v = random.choice(self.bg_video_infos or video_infos)
+                idx = random.randint(self.start_index, int(v['total_frames']) - 1 + self.start_index)
+                paths.append(osp.join(v['frame_dir'], self.tmpl.format(idx)))
+        streams = list(self.decoder.pool.map(self._read, paths))
+        infos = [jpeg_parse(s) for s in streams]
+        out = torch.empty(B, self.input_size, self.input_size, 3, dtype=torch.float32, device=self.device)
+        groups = {}
+        for i, inf in enumerate(infos):
+            groups.setdefault((inf.width, inf.height), []).append(i)
+        for idx in groups.values():            # the crop draws stay in sample order inside a size group; sizes rarely differ
+            bg = self.decoder.decode([streams[i] for i in idx])
+            out[torch.as_tensor(idx, device=self.device)] = self.bg_front(bg)
+        return out
+
+    def __call__(self, video_infos: List[dict], phase: str):
+        B = len(video_infos)
+        frames, inds = self._frames(video_infos, test_mode=phase != 'train')
+        H, W = int(frames.shape[2]), int(frames.shape[3])
+        Wr, Hr = rescale_size(W, H, (-1, self.short_edge))
+        from . import kernels as K
+        frames = K.resize_linear_u8(frames, Hr, Wr)
+        extra = {}
+        if phase == 'train':
+            bg = self._backgrounds(B, video_infos)
+            imgs, rand_flags, _ = self.train_front(frames, bg, as_nchw=True)
+            extra['randAug'] = rand_flags
+        elif phase == 'test':
+            imgs = self.test.as_nchw(frames)
+        else:
+            imgs = self.center.as_nchw(frames)
+        dev = self.device
+        return {**extra, 'imgs': imgs,
+                'label': torch.tensor([[v['label']] for v in video_infos], dtype=torch.int64, device=dev),
+                'frame_dir': [v['frame_dir'] for v in video_infos],
+                'total_frames': torch.tensor([int(v['total_frames']) for v in video_infos], dtype=torch.int64, device=dev),
+                'clip_len': torch.ones(B, dtype=torch.int64, device=dev),
+                'num_clips': torch.full((B,), self.T, dtype=torch.int64, device=dev),
+                'frame_inds': torch.from_numpy(inds).to(dev)}

@@ -159,3 +159,46 @@ class CropFrontEnd:
 
     def as_nchw(self, frames_u8: torch.Tensor) -> torch.Tensor:
         return self._run(frames_u8, False)[1]
+
+
+class MultiScaleCropResize:
+    """``MultiScaleCrop(input_size, scales, max_wh_scale_gap, random_crop, num_fixed_crops)`` + ``Resize(scale=(w, h), keep_ratio=False)``
+    of the train pipeline (configs/ucf101/bgmix_plus_randAug/...py:129-136; UPSTREAM mmaction2 0.24 semantics) as the ``crop_resize``
+    stage of ``TrainClipFrontEnd``: one crop box per clip (all frames of a sample share it), drawn with two ``random.choice`` calls
+    as upstream does (sizes first, then one of the 5 / 13 fixed offsets; ``random_crop=True``: two ``random.randint``), then crop +
+    ``cv2.resize(INTER_LINEAR)`` in one kernel (``bdv_resize_linear_u8``; parity unpinned, see include/bdvcil_hip.h)."""
+
+    def __init__(self, input_size=224, scales=(1, 0.875, 0.75, 0.66), max_wh_scale_gap=1, random_crop=False, num_fixed_crops=5,
+                 out_size=None):
+        self.input_size = (input_size, input_size) if isinstance(input_size, int) else tuple(input_size)       # (w, h)
+        self.scales, self.gap, self.random_crop = tuple(scales), int(max_wh_scale_gap), bool(random_crop)
+        if num_fixed_crops not in (5, 13):
+            raise ValueError(f'num_fixed_crops must be 5 or 13, got {num_fixed_crops}')
+        self.num_fixed_crops = num_fixed_crops
+        self.out_size = self.input_size if out_size is None else tuple(out_size)                               # (w, h) of the Resize after it
+
+    def draw(self, img_w: int, img_h: int):
+        import random
+        base = min(img_w, img_h)
+        sizes = [int(base * s) for s in self.scales]
+        cand = [[w, h] for i, h in enumerate(sizes) for j, w in enumerate(sizes) if abs(i - j) <= self.gap]
+        crop = list(random.choice(cand))
+        for i in range(2):
+            if abs(crop[i] - self.input_size[i]) < 3:
+                crop[i] = self.input_size[i]
+        cw, ch = crop
+        if self.random_crop:
+            return random.randint(0, img_w - cw), random.randint(0, img_h - ch), cw, ch
+        ws, hs = (img_w - cw) // 4, (img_h - ch) // 4
+        offs = [(0, 0), (4 * ws, 0), (0, 4 * hs), (4 * ws, 4 * hs), (2 * ws, 2 * hs)]
+        if self.num_fixed_crops == 13:
+            offs += [(0, 2 * hs), (4 * ws, 2 * hs), (2 * ws, 4 * hs), (2 * ws, 0), (ws, hs), (3 * ws, hs), (ws, 3 * hs), (3 * ws, 3 * hs)]
+        x, y = random.choice(offs)
+        return x, y, cw, ch
+
+    def __call__(self, frames_u8: torch.Tensor, bg=None, boxes=None):
+        B, _, H, W, _ = frames_u8.shape
+        if boxes is None:
+            boxes = [self.draw(W, H) for _ in range(B)]
+        self.last_boxes = boxes
+        return K.resize_linear_u8(frames_u8, self.out_size[1], self.out_size[0], boxes), bg

@@ -756,6 +756,32 @@ def bg_resize_crop_u8(bg, size, crop_h, crop_w, top, left):
     return out
 
 
+def resize_linear_u8(frames, Hd: int, Wd: int, boxes=None):
+    """``cv2.resize(..., INTER_LINEAR)`` of uint8 frames (.., Hs, Ws, 3) -> (.., Hd, Wd, 3).  ``boxes``: None, or for frames of shape
+    (B, T, Hs, Ws, 3) a list / (B, 4) array of per-clip crops (x0, y0, w, h) that are cut out and resized in the same pass
+    (MultiScaleCrop + Resize)."""
+    _chk(frames, dtype=torch.uint8, name='frames')
+    if frames.dim() < 3 or frames.shape[-1] != 3:
+        raise ValueError(f'resize_linear_u8: expected (..., H, W, 3), got {tuple(frames.shape)}')
+    Hs, Ws = int(frames.shape[-3]), int(frames.shape[-2])
+    lead = tuple(frames.shape[:-3])
+    N = 1
+    for d in lead:
+        N *= int(d)
+    out = torch.empty(lead + (int(Hd), int(Wd), 3), dtype=torch.uint8, device=frames.device)
+    dev_boxes, host_boxes, per = None, None, 1
+    if boxes is not None:
+        if frames.dim() != 5:
+            raise ValueError('resize_linear_u8: per-clip boxes need frames of shape (B, T, H, W, 3)')
+        hb = torch.as_tensor(boxes, dtype=torch.int32).reshape(-1, 4).contiguous()
+        if hb.shape[0] != frames.shape[0]:
+            raise ValueError(f'resize_linear_u8: {hb.shape[0]} boxes for {frames.shape[0]} clips')
+        host_boxes, dev_boxes, per = hb, hb.to(frames.device), int(frames.shape[1])
+    check(lib().bdv_resize_linear_u8(_p(frames), N, Hs, Ws, _p(dev_boxes), per, host_boxes.data_ptr() if host_boxes is not None else None,
+                                     _p(out), int(Hd), int(Wd), _stream()), 'bdv_resize_linear_u8')
+    return out
+
+
 def crop_normalize_u8(frames, crops, crop_h, crop_w, mean, std, want_nhwc4=True, want_nchw=False):
     """frames (B,T,H,W,3) u8; crops = [(x_offset, y_offset, flip), ...] -> (o4 (B*n*T, ch, cw, 4) | None,
     oc (B, n*T, 3, ch, cw) | None), crop-major frame order."""

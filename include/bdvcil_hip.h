@@ -415,6 +415,15 @@ size_t bdv_randaug_workspace_bytes(int B, int T, int H, int W);
 int bdv_randaug_apply(const uint8_t* in, uint8_t* out, const int32_t* op_i, const double* op_d, int B, int T, int H,
                       int W, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Resize / MultiScaleCrop + Resize of the frame pipeline (configs/ucf101/bgmix_plus_randAug/...py:127-136; UPSTREAM mmaction2
+ * Resize -> mmcv.imresize('bilinear') -> cv2.resize(INTER_LINEAR) on uint8 images): OpenCV's published fixed-point arithmetic
+ * (11-bit weights, horizontal then vertical pass, the 2x2 box mean for an exact 2x shrink), PARITY UNPINNED -- cv2 is in neither
+ * the reference tree nor this image (oracle/resize_oracle.py).  src (N,Hs,Ws,3) uint8 -> dst (N,Hd,Wd,3) uint8.  boxes: NULL (the
+ * whole frame) or one (x0, y0, w, h) int32 quadruple per group of frames_per_box consecutive frames (a clip shares its crop), given
+ * on the device (read by the kernel) AND on the host (validated against the frame before the launch). */
+int bdv_resize_linear_u8(const uint8_t* src, int N, int Hs, int Ws, const int32_t* boxes, int frames_per_box,
+                         const int32_t* boxes_host, uint8_t* dst, int Hd, int Wd, void* stream);
+
 /* ---- JPEG frame decode ----------------------------------------------
  * The first stage of every pipeline of the configs: RawFrameDecode (configs/ucf101/bgmix_plus_randAug/
  * bgmix_seed_1000_inc_10_stages_bgmix_plus_randAug.py:126, :144, :160; UPSTREAM mmaction2 RawFrameDecode ->
