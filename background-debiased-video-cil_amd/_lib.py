@@ -107,6 +107,7 @@ SIGNATURES = {
     'bdv_resize_linear_u8': (c_int, [P, c_int, c_int, c_int, P, c_int, P, P, c_int, c_int, P]),
     'bdv_jpeg_parse': (c_int, [P, c_size_t, POINTER(JpegInfo)]),
     'bdv_jpeg_entropy_decode': (c_int, [P, c_size_t, POINTER(JpegInfo), P]),
+    'bdv_jpeg_entropy_decode_batch': (c_int, [P, P, c_int, POINTER(JpegInfo), P, P, c_int]),
     'bdv_jpeg_workspace_bytes': (c_size_t, [POINTER(JpegInfo), c_int]),
     'bdv_jpeg_reconstruct_u8': (c_int, [P, P, POINTER(JpegInfo), c_int, P, c_size_t, P, P]),
     'bdv_crop_normalize_u8': (c_int, [P, P, c_int, c_int, c_int, _F3, _F3, P, P, c_int, c_int, c_int, c_int, P]),

@@ -10,6 +10,11 @@
 // Both kernels are byte / integer work bound by HBM traffic (2 bytes of coefficients in, 1 byte out per sample; then 1.5 - 3 bytes
 // in, 3 out per pixel): no LDS, no MFMA -- one thread per block resp. per pixel, 16-byte loads.
 #include <string.h>
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -25,18 +30,21 @@ struct HuffTable {
   int mincode[17];
   int valptr[17];
   unsigned char sym[256];
+  unsigned short look[512];   // the next 9 bits of the stream -> (code length << 8) | symbol for codes of <= 9 bits, else 0
   void build(const unsigned char* counts, const unsigned char* symbols, int n) {
+    memset(look, 0, sizeof(look));
+    memcpy(sym, symbols, n);
     int code = 0, k = 0;
     for (int len = 1; len <= 16; ++len) {
       valptr[len] = k;
       mincode[len] = code;
-      code += counts[len - 1];
-      k += counts[len - 1];
+      for (int i = 0; i < counts[len - 1]; ++i, ++code, ++k)
+        if (len <= 9 && k < 256 && code < (1 << len))
+          for (int fill = 0; fill < (1 << (9 - len)); ++fill) look[((code << (9 - len)) | fill) & 511] = (unsigned short)((len << 8) | sym[k]);
       maxcode[len] = counts[len - 1] ? code - 1 : -1;
       code <<= 1;
     }
     maxcode[17] = 1 << 30;
-    memcpy(sym, symbols, n);
     defined = true;
   }
 };
@@ -219,9 +227,14 @@ struct BitReader {
       have += 8;
     }
   }
-  inline int get(int k) {
+  // one symbol needs at most 16 code bits + 15 value bits: top the window up once per symbol, then peek / skip without checks
+  inline void ensure() {
+    if (have < 32) fill();
+  }
+  inline unsigned peek(int k) const { return (unsigned)(acc >> (have - k)) & ((1u << k) - 1); }
+  inline void skip(int k) { have -= k; }
+  inline int get(int k) {   // after ensure(): k <= 16
     if (k == 0) return 0;
-    if (have < k) fill();
     have -= k;
     return (int)((acc >> have) & ((1u << k) - 1));
   }
@@ -234,11 +247,22 @@ struct BitReader {
 };
 
 inline int huff_decode(BitReader& br, const HuffTable& t) {
-  int code = br.get(1), len = 1;
-  while (code > t.maxcode[len]) {
-    code = (code << 1) | br.get(1);
-    if (++len > 16) return 0;
+  br.ensure();
+  const unsigned e = t.look[br.peek(9)];
+  if (e) {
+    br.skip(e >> 8);
+    return e & 255;
   }
+  int len = 10;
+  int code = (int)br.peek(10);
+  while (code > t.maxcode[len]) {
+    if (++len > 16) {
+      br.skip(16);
+      return 0;   // not a code of this table (corrupt data): decode on, as the IJG decoder does after its warning
+    }
+    code = (int)br.peek(len);
+  }
+  br.skip(len);
   return t.sym[(t.valptr[len] + code - t.mincode[len]) & 255];
 }
 
@@ -246,6 +270,7 @@ inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 :
 
 inline void decode_block(BitReader& br, const HuffTable& dct, const HuffTable& act, int& pred, short* blk) {
   int s = huff_decode(br, dct);
+  if (s > 16) s = 16;   // (corrupt data: no valid DC category is that large; keep the bit window's contract)
   if (s) pred += extend(br.get(s), s);
   blk[0] = (short)pred;
   for (int k = 1; k < 64;) {
@@ -514,6 +539,43 @@ extern "C" int bdv_jpeg_entropy_decode(const unsigned char* data, size_t n, cons
             }
         }
       }
+  }
+  return BDV_OK;
+}
+
+extern "C" int bdv_jpeg_entropy_decode_batch(const unsigned char* const* data, const size_t* sizes, int n, const bdv_jpeg_info* info,
+                                             short* coefs, unsigned short* qts, int threads) {
+  BDV_REQUIRE(data && sizes && info && coefs && qts && n > 0, "bdv_jpeg_entropy_decode_batch: null pointer / empty batch");
+  BDV_REQUIRE(threads >= 1 && threads <= 256, "bdv_jpeg_entropy_decode_batch: %d threads (1..256)", threads);
+  std::atomic<int> next(0), failed(0);
+  std::mutex mu;
+  std::string first_error;
+  int first_code = BDV_OK;
+  auto worker = [&]() {
+    for (int i = next.fetch_add(1); i < n && !failed.load(); i = next.fetch_add(1)) {
+      short* dst = coefs + (size_t)i * info->coef_count;
+      int e = data[i] ? bdv_jpeg_entropy_decode(data[i], sizes[i], info, dst) : BDV_EINVAL;
+      if (e == BDV_OK) {   // the tables of THIS stream (bdv_jpeg_entropy_decode has just parsed it on this thread)
+        bdv_jpeg_info mine;
+        fill_info(g_parsed, &mine);
+        memcpy(qts + (size_t)i * 3 * 64, mine.qt, sizeof(mine.qt));
+      } else {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!failed.exchange(1)) {
+          first_code = e;
+          first_error = "image " + std::to_string(i) + ": " + (data[i] ? bdv_last_error() : "null stream");
+        }
+      }
+    }
+  };
+  const int nt = threads < n ? threads : n;
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& th : pool) th.join();
+  if (failed.load()) {
+    bdv_set_error("bdv_jpeg_entropy_decode_batch: %s", first_error.c_str());
+    return first_code;
   }
   return BDV_OK;
 }

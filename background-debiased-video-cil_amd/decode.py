@@ -2,7 +2,7 @@
 
 The reference decodes on CPU workers (UPSTREAM mmaction2 ``RawFrameDecode`` -> ``mmcv.imfrombytes(channel_order='rgb')`` ->
 ``cv2.imdecode``: libjpeg-turbo's defaults; configs/ucf101/bgmix_plus_randAug/...py:126).  Here the Huffman stage -- a serial bit
-stream -- runs on host threads (``bdv_jpeg_entropy_decode``; ctypes releases the GIL, one image per thread), the coefficients cross
+stream -- runs on host threads (``bdv_jpeg_entropy_decode_batch``: std::thread workers inside the library, one image each), the coefficients cross
 PCIe once as int16 (about the size of the decoded image), and dequantisation, inverse DCT, chroma upsampling and colour conversion
 run as two launches for the whole batch (``bdv_jpeg_reconstruct_u8``), bit-identical to libjpeg-turbo (tests/test_jpeg_gpu.py).
 The output is the ``(N, H, W, 3)`` uint8 layout ``RandAugment`` / ``TrainClipFrontEnd`` / ``CropFrontEnd`` take."""
@@ -47,7 +47,8 @@ class JpegDecoder:
 
     def __init__(self, device='cuda', threads: int = 8):
         self.device = torch.device(device)
-        self.pool = ThreadPoolExecutor(max_workers=max(1, int(threads)))
+        self.threads = max(1, int(threads))
+        self.pool = ThreadPoolExecutor(max_workers=self.threads)      # file reads and header parses; the Huffman stage threads in C
 
     def _group(self, streams: Sequence[bytes]):
         infos = list(self.pool.map(jpeg_parse, streams))
@@ -77,12 +78,10 @@ class JpegDecoder:
         pin = self.device.type == 'cuda'
         coefs = torch.empty(n, info.coef_count, dtype=torch.int16, pin_memory=pin)
         qts = torch.zeros(n, 3, 64, dtype=torch.int16, pin_memory=pin)
-        cn, qn = coefs.numpy(), qts.numpy().view(np.uint16)
-
-        def work(i):
-            jpeg_entropy_decode(streams[i], infos[i], cn[i])
-            qn[i] = np.ctypeslib.as_array(infos[i].qt)
-        list(self.pool.map(work, range(n)))
+        ptrs = (ctypes.c_char_p * n)(*streams)
+        sizes = (ctypes.c_size_t * n)(*[len(s) for s in streams])
+        check(lib().bdv_jpeg_entropy_decode_batch(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(sizes, ctypes.c_void_p), n, ctypes.byref(info),
+                                                  coefs.data_ptr(), qts.data_ptr(), self.threads), 'bdv_jpeg_entropy_decode_batch')
         coefs_d, qts_d = coefs.to(self.device, non_blocking=True), qts.to(self.device, non_blocking=True)
         ws_bytes = lib().bdv_jpeg_workspace_bytes(ctypes.byref(info), n)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)

@@ -449,6 +449,11 @@ typedef struct {
 } bdv_jpeg_info;
 int bdv_jpeg_parse(const unsigned char* data, size_t n, bdv_jpeg_info* info);
 int bdv_jpeg_entropy_decode(const unsigned char* data, size_t n, const bdv_jpeg_info* info, short* coefs);
+/* Step 2 for n streams of ONE geometry on `threads` host threads (std::thread; the caller's thread is one of them): coefs
+ * (n, coef_count) int16 and qts (n, 3, 64) uint16 are HOST buffers (pinned, for the upload); returns the first failing image's
+ * error.  What decode.JpegDecoder calls per batch. */
+int bdv_jpeg_entropy_decode_batch(const unsigned char* const* data, const size_t* sizes, int n, const bdv_jpeg_info* info,
+                                  short* coefs, unsigned short* qts, int threads);
 size_t bdv_jpeg_workspace_bytes(const bdv_jpeg_info* info, int B);
 int bdv_jpeg_reconstruct_u8(const short* coefs, const unsigned short* qts, const bdv_jpeg_info* info, int B, void* workspace,
                             size_t workspace_bytes, unsigned char* rgb, void* stream);

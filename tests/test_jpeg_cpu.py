@@ -110,3 +110,38 @@ def test_errors_are_reported_not_guessed():
     data = a.getvalue()
     _, co = jpeg_entropy_decode(data[:len(data) - 40])
     assert co.size == info.coef_count
+
+
+def test_batch_host_stage_equals_per_image_calls():
+    """``bdv_jpeg_entropy_decode_batch`` (std::thread workers inside the library) == one ``bdv_jpeg_entropy_decode`` per stream; the
+    first failing stream's error comes back with its index."""
+    import ctypes
+    from PIL import Image
+    from bdvcil_amd._lib import HipExtensionError, check, lib
+    from bdvcil_amd.decode import jpeg_entropy_decode, jpeg_parse
+    rng = np.random.default_rng(9)
+    streams = []
+    for i in range(13):
+        buf = io.BytesIO()
+        Image.fromarray(_picture(40, 56, i % 3, rng)).save(buf, 'JPEG', quality=50 + 4 * i, subsampling=2)
+        streams.append(buf.getvalue())
+    info = jpeg_parse(streams[0])
+
+    def run(ss, threads):
+        n = len(ss)
+        coefs = np.full((n, info.coef_count), 7, dtype=np.int16)
+        qts = np.zeros((n, 3, 64), dtype=np.uint16)
+        ptrs = (ctypes.c_char_p * n)(*ss)
+        sizes = (ctypes.c_size_t * n)(*[len(s) for s in ss])
+        check(lib().bdv_jpeg_entropy_decode_batch(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(sizes, ctypes.c_void_p), n, ctypes.byref(info),
+                                                  coefs.ctypes.data, qts.ctypes.data, threads), 'bdv_jpeg_entropy_decode_batch')
+        return coefs, qts
+    for threads in (1, 4, 32):
+        coefs, qts = run(streams, threads)
+        for i, s in enumerate(streams):
+            inf, c = jpeg_entropy_decode(s)
+            assert np.array_equal(coefs[i], c) and np.array_equal(qts[i], np.ctypeslib.as_array(inf.qt))
+    buf = io.BytesIO()
+    Image.fromarray(_picture(40, 64, 0, rng)).save(buf, 'JPEG')
+    with pytest.raises((HipExtensionError, RuntimeError), match='image 5.*geometry'):
+        run(streams[:5] + [buf.getvalue()] + streams[5:], 3)
