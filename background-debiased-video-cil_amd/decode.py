@@ -50,6 +50,24 @@ class JpegDecoder:
         self.threads = max(1, int(threads))
         self.pool = ThreadPoolExecutor(max_workers=self.threads)      # file reads and header parses; the Huffman stage threads in C
 
+    def _staging(self, ncoef: int, nqt: int):
+        """Two pinned staging sets used in turn (a fresh pinned allocation per batch costs several milliseconds, and torch's
+        host allocator cannot hand a block back while its upload is still queued): (coefs, qts, event) -- the event marks the
+        last upload from the set; waited on before the host threads overwrite it."""
+        pin = self.device.type == 'cuda'
+        if not hasattr(self, '_sets'):
+            self._sets, self._turn = [None, None], 0
+        self._turn ^= 1
+        cur = self._sets[self._turn]
+        if cur is None or cur[0].numel() < ncoef or cur[1].numel() < nqt:
+            cur = (torch.empty(max(ncoef, cur[0].numel() if cur else 0), dtype=torch.int16, pin_memory=pin),
+                   torch.empty(max(nqt, cur[1].numel() if cur else 0), dtype=torch.int16, pin_memory=pin),
+                   torch.cuda.Event() if pin else None)
+            self._sets[self._turn] = cur
+        elif cur[2] is not None:
+            cur[2].synchronize()
+        return cur
+
     def _group(self, streams: Sequence[bytes]):
         infos = list(self.pool.map(jpeg_parse, streams))
         groups = {}
@@ -60,6 +78,13 @@ class JpegDecoder:
     def decode(self, streams: Sequence[bytes]) -> torch.Tensor:
         if len(streams) == 0:
             raise ValueError('JpegDecoder.decode: empty batch')
+        # the common case -- every stream has the first one's geometry (frames of one dataset) -- needs no per-stream Python work: the
+        # batch call checks each stream against `info` itself and names the first that differs; only then are the streams grouped
+        try:
+            return self._decode_group(list(streams), [jpeg_parse(streams[0])])
+        except RuntimeError as e:
+            if 'does not have the geometry' not in str(e):
+                raise
         infos, groups = self._group(streams)
         sizes = {(k[0], k[1]) for k in groups}
         if len(sizes) != 1:
@@ -75,9 +100,8 @@ class JpegDecoder:
 
     def _decode_group(self, streams: List[bytes], infos: List[JpegInfo]) -> torch.Tensor:
         n, info = len(streams), infos[0]
-        pin = self.device.type == 'cuda'
-        coefs = torch.empty(n, info.coef_count, dtype=torch.int16, pin_memory=pin)
-        qts = torch.zeros(n, 3, 64, dtype=torch.int16, pin_memory=pin)
+        coefs, qts, done = self._staging(n * info.coef_count, n * 192)
+        coefs, qts = coefs[:n * info.coef_count].view(n, info.coef_count), qts[:n * 192].view(n, 3, 64)
         ptrs = (ctypes.c_char_p * n)(*streams)
         sizes = (ctypes.c_size_t * n)(*[len(s) for s in streams])
         check(lib().bdv_jpeg_entropy_decode_batch(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(sizes, ctypes.c_void_p), n, ctypes.byref(info),
@@ -89,7 +113,9 @@ class JpegDecoder:
         from .kernels import _p, _stream
         check(lib().bdv_jpeg_reconstruct_u8(_p(coefs_d), _p(qts_d), ctypes.byref(info), n, _p(ws), ws_bytes, _p(rgb), _stream()),
               'bdv_jpeg_reconstruct_u8')
-        return rgb      # (torch's pinned-memory allocator keeps the staging blocks until the asynchronous copies have run)
+        if done is not None:
+            done.record()         # the staging set may be refilled once the stream has passed the uploads
+        return rgb
 
     def decode_clips(self, clips: Sequence[Sequence[bytes]]) -> torch.Tensor:
         """``clips``: B lists of T streams each -> (B, T, H, W, 3) uint8."""
