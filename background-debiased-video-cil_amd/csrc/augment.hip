@@ -390,47 +390,89 @@ __device__ __forceinline__ ResizeAxis resize_axis_y(int d, double scale, int ssi
   return r;
 }
 
-// one thread per output pixel (3 channels); boxes: per group of T frames (x0, y0, w, h) inside the source frame, or NULL = the whole frame
-__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, const int32_t* __restrict__ boxes,
-                                                                uint8_t* __restrict__ dst, int N, int T, int Hs, int Ws, int Hd, int Wd) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long per = (long long)Hd * Wd;
-  if (t >= per * N) return;
-  const int n = (int)(t / per);
-  const int pix = (int)(t - n * per);
-  const int dy = pix / Wd, dx = pix - dy * Wd;
-  int x0 = 0, y0 = 0, bw = Ws, bh = Hs;
-  if (boxes != nullptr) {
-    const int32_t* b = boxes + 4 * (n / T);
-    x0 = b[0];
-    y0 = b[1];
-    bw = b[2];
-    bh = b[3];
-  }
-  const uint8_t* base = src + ((size_t)n * Hs + y0) * Ws * 3 + (size_t)x0 * 3;
-  const size_t pitch = (size_t)Ws * 3;
-  uint8_t* o = dst + (size_t)t * 3;
-  if (bw == Wd && bh == Hd) {   // same size: cv::resize copies
+struct ResizeBox {
+  const uint8_t* base;   // first pixel of the box
+  size_t pitch;
+  int bw, bh, mode;      // mode 0: resample, 1: copy (same size), 2: 2x2 box mean (exact 2x shrink)
+  double scale_x, scale_y;
+};
+
+// one output pixel of a box -> packed 0x00BBGGRR
+__device__ __forceinline__ unsigned resize_pixel(const ResizeBox& b, int dx, int dy) {
+  unsigned out = 0;
+  if (b.mode == 1) {   // same size: cv::resize copies
 #pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] = base[dy * pitch + dx * 3 + c];
-    return;
+    for (int c = 0; c < 3; ++c) out |= (unsigned)b.base[dy * b.pitch + dx * 3 + c] << (8 * c);
+    return out;
   }
-  if (bw == 2 * Wd && bh == 2 * Hd) {   // exact 2x shrink: INTER_LINEAR is replaced by the fast INTER_AREA (2x2 mean, rounded)
-    const uint8_t* p = base + (size_t)(2 * dy) * pitch + (size_t)(2 * dx) * 3;
+  if (b.mode == 2) {   // exact 2x shrink: INTER_LINEAR is replaced by the fast INTER_AREA (2x2 mean, rounded)
+    const uint8_t* p = b.base + (size_t)(2 * dy) * b.pitch + (size_t)(2 * dx) * 3;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] = (uint8_t)((p[c] + p[3 + c] + p[pitch + c] + p[pitch + 3 + c] + 2) >> 2);
-    return;
+    for (int c = 0; c < 3; ++c) out |= (unsigned)((p[c] + p[3 + c] + p[b.pitch + c] + p[b.pitch + 3 + c] + 2) >> 2) << (8 * c);
+    return out;
   }
-  const double scale_x = 1.0 / ((double)Wd / bw), scale_y = 1.0 / ((double)Hd / bh);
-  const ResizeAxis ax = resize_axis_x(dx, scale_x, bw), ay = resize_axis_y(dy, scale_y, bh);
-  const uint8_t* r0 = base + (size_t)ay.s0 * pitch;
-  const uint8_t* r1 = base + (size_t)ay.s1 * pitch;
+  const ResizeAxis ax = resize_axis_x(dx, b.scale_x, b.bw), ay = resize_axis_y(dy, b.scale_y, b.bh);
+  const uint8_t* r0 = b.base + (size_t)ay.s0 * b.pitch;
+  const uint8_t* r1 = b.base + (size_t)ay.s1 * b.pitch;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const int h0 = r0[ax.s0 * 3 + c] * ax.a0 + r0[ax.s1 * 3 + c] * ax.a1;
     const int h1 = r1[ax.s0 * 3 + c] * ax.a0 + r1[ax.s1 * 3 + c] * ax.a1;
     const int v = (((ay.a0 * (h0 >> 4)) >> 16) + ((ay.a1 * (h1 >> 4)) >> 16) + 2) >> 2;
-    o[c] = (uint8_t)v;
+    out |= (unsigned)(v & 255) << (8 * c);
+  }
+  return out;
+}
+
+// grid (pixel groups of one frame, frame): four consecutive output pixels of a frame per thread -- one integer division and the
+// box's two double divisions per THREAD (the first form did them, and a 64-bit division, per pixel and was bound by that arithmetic);
+// aligned dword stores when a frame is a whole number of dwords.  boxes: per group of T frames (x0, y0, w, h) inside the source
+// frame, or NULL = the whole frame.
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, const int32_t* __restrict__ boxes,
+                                                                uint8_t* __restrict__ dst, int T, int Hs, int Ws, int Hd, int Wd) {
+  const unsigned npix = (unsigned)Hd * (unsigned)Wd;
+  const unsigned p0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (p0 >= npix) return;
+  const unsigned n = blockIdx.y;
+  int x0 = 0, y0 = 0;
+  ResizeBox b;
+  b.bw = Ws;
+  b.bh = Hs;
+  if (boxes != nullptr) {
+    const int32_t* q = boxes + 4 * (n / (unsigned)T);
+    x0 = q[0];
+    y0 = q[1];
+    b.bw = q[2];
+    b.bh = q[3];
+  }
+  b.pitch = (size_t)Ws * 3;
+  b.base = src + ((size_t)n * Hs + y0) * b.pitch + (size_t)x0 * 3;
+  b.mode = (b.bw == Wd && b.bh == Hd) ? 1 : (b.bw == 2 * Wd && b.bh == 2 * Hd) ? 2 : 0;
+  b.scale_x = 1.0 / ((double)Wd / b.bw);
+  b.scale_y = 1.0 / ((double)Hd / b.bh);
+  int dy = (int)(p0 / (unsigned)Wd), dx = (int)(p0 - (unsigned)dy * (unsigned)Wd);
+  unsigned px[4];
+  const int cnt = npix - p0 < 4u ? (int)(npix - p0) : 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    px[k] = k < cnt ? resize_pixel(b, dx, dy) : 0u;
+    if (++dx == Wd) {
+      dx = 0;
+      ++dy;
+    }
+  }
+  uint8_t* out = dst + ((size_t)n * npix + p0) * 3;
+  if (cnt == 4 && (npix & 3u) == 0u) {
+    unsigned* o = reinterpret_cast<unsigned*>(out);
+    o[0] = px[0] | (px[1] << 24);
+    o[1] = (px[1] >> 8) | (px[2] << 16);
+    o[2] = (px[2] >> 16) | (px[3] << 8);
+  } else {
+    for (int k = 0; k < cnt; ++k) {
+      out[3 * k] = (uint8_t)px[k];
+      out[3 * k + 1] = (uint8_t)(px[k] >> 8);
+      out[3 * k + 2] = (uint8_t)(px[k] >> 16);
+    }
   }
 }
 
@@ -449,9 +491,10 @@ extern "C" int bdv_resize_linear_u8(const uint8_t* src, int N, int Hs, int Ws, c
                   "bdv_resize_linear_u8: box %d = (x %d, y %d, w %d, h %d) leaves the %d x %d frame", i, b[0], b[1], b[2], b[3], Ws, Hs);
     }
   }
-  const long long total = (long long)N * Hd * Wd;
-  BDV_REQUIRE(total / 256 < (1ll << 31), "bdv_resize_linear_u8: batch too large for one launch");
-  hipLaunchKernelGGL(resize_linear_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, boxes, dst, N,
+  BDV_REQUIRE(N <= 65535 && (long long)Hd * Wd < (1ll << 31) && (long long)Hs * Ws < (1ll << 29), "bdv_resize_linear_u8: at most 65535 frames per call; frame too large");
+  BDV_REQUIRE((((uintptr_t)dst) & 3) == 0, "bdv_resize_linear_u8: dst must be 4-byte aligned");
+  const unsigned groups = ((unsigned)Hd * (unsigned)Wd + 3u) / 4u;   // four pixels per thread
+  hipLaunchKernelGGL(resize_linear_u8_kernel, dim3((groups + 255u) / 256u, (unsigned)N), dim3(256), 0, (hipStream_t)stream, src, boxes, dst,
                      boxes ? frames_per_box : 1, Hs, Ws, Hd, Wd);
   BDV_LAUNCH_CHECK("bdv_resize_linear_u8");
   return BDV_OK;

@@ -8,7 +8,8 @@
 // GPU for a whole batch of equal-geometry images in two launches (bdv_jpeg_reconstruct_u8): dequantise + 8x8 inverse DCT -> component
 // planes, then upsample + colour conversion -> interleaved RGB uint8, the (B, H, W, 3) layout RandAugment and the front-ends take.
 // Both kernels are byte / integer work bound by HBM traffic (2 bytes of coefficients in, 1 byte out per sample; then 1.5 - 3 bytes
-// in, 3 out per pixel): no LDS, no MFMA -- one thread per block resp. per pixel, 16-byte loads.
+// in, 3 out per pixel): no MFMA; coalesced 16-byte loads staged through LDS for the block kernel, aligned dword stores for the pixel
+// kernel.
 #include <string.h>
 #include <atomic>
 #include <mutex>
@@ -347,21 +348,36 @@ __device__ __forceinline__ unsigned range_limit_idct(int x) {
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-// one thread per 8x8 block: 8 x 16-byte loads of coefficients, 8 x 8-byte stores of samples
+// One thread per 8x8 block, 256 blocks per workgroup.  The coefficients of consecutive blocks are contiguous (128 bytes each, also
+// across components and images), so the workgroup's 32 KB are fetched with fully coalesced 16-byte loads and handed to their threads
+// through LDS: block b's chunk r sits at b * 144 + r * 16 -- the 16-byte pad per block makes the per-thread 16-byte reads of 16
+// neighbouring lanes fall on all 64 banks once.  A thread then holds its block in registers for both passes and writes 8 x 8 bytes;
+// neighbouring threads are neighbouring blocks of a block row, i.e. their row stores are contiguous.
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(const short* __restrict__ coefs, const unsigned short* __restrict__ qts,
                                                          unsigned char* __restrict__ planes, JpegGeom g, int B) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= g.blocks_total * B) return;
-  const int img = t / g.blocks_total, bi = t - img * g.blocks_total;
+  __shared__ __attribute__((aligned(16))) unsigned char stage[256 * 144];
+  const unsigned nblk = (unsigned)g.blocks_total * (unsigned)B;     // < 2^31 (checked on the host): 32-bit index arithmetic throughout
+  const unsigned first = blockIdx.x * 256u;
+  const int tid = threadIdx.x;
+  const uint4* src4 = reinterpret_cast<const uint4*>(coefs) + (size_t)first * 8;   // 8 chunks of 16 bytes per block
+  const unsigned chunks_left = (nblk - first < 256u ? nblk - first : 256u) * 8u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = i * 256 + tid;
+    if ((unsigned)c < chunks_left) *reinterpret_cast<uint4*>(stage + (c >> 3) * 144 + (c & 7) * 16) = src4[c];
+  }
+  __syncthreads();
+  const unsigned t = first + tid;
+  if (t >= nblk) return;
+  const int img = (int)(t / (unsigned)g.blocks_total), bi = (int)(t - (unsigned)img * (unsigned)g.blocks_total);
   const int c = bi >= g.block_first[2] ? 2 : bi >= g.block_first[1] ? 1 : 0;
   const int b = bi - g.block_first[c];
   const int by = b / g.bw[c], bx = b - by * g.bw[c];
-  const short* src = coefs + (size_t)img * g.coef_count + g.coef_off[c] + (size_t)b * 64;
   const unsigned short* qt = qts + ((size_t)img * 3 + c) * 64;
   int m[8][8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const s16x8 cv = *reinterpret_cast<const s16x8*>(src + 8 * r);
+    const s16x8 cv = *reinterpret_cast<const s16x8*>(stage + tid * 144 + r * 16);
     const s16x8 qv = *reinterpret_cast<const s16x8*>(qt + 8 * r);
 #pragma unroll
     for (int k = 0; k < 8; ++k) m[r][k] = (int)cv[k] * (int)(unsigned short)qv[k];
@@ -415,30 +431,51 @@ __device__ __forceinline__ int chroma_at(const unsigned char* __restrict__ p, in
 
 __device__ __forceinline__ unsigned clamp255(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
 
-// one thread per pixel; fixed-point YCbCr -> RGB with 16 fraction bits and the decoder's rounding
-__global__ __launch_bounds__(256) void jpeg_color_kernel(const unsigned char* __restrict__ planes, unsigned char* __restrict__ rgb, JpegGeom g, int B) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long npix = (long long)g.W * g.H;
-  if (t >= npix * B) return;
-  const int img = (int)(t / npix);
-  const int pix = (int)(t - img * npix);
-  const int y = pix / g.W, x = pix - y * g.W;
-  const unsigned char* base = planes + (size_t)img * g.plane_bytes;
+// Fixed-point YCbCr -> RGB with 16 fraction bits and the decoder's rounding; one pixel -> packed 0x00BBGGRR.
+__device__ __forceinline__ unsigned jpeg_pixel(const unsigned char* __restrict__ base, const JpegGeom& g, int x, int y) {
   const int Y = base[g.plane_off[0] + (size_t)y * 8 * g.bw[0] + x];
-  unsigned r, gg, b;
-  if (g.ncomp == 1) {
-    r = gg = b = Y;
-  } else {
-    const int cb = chroma_at(base + g.plane_off[1], 8 * g.bw[1], g.dw[1], g.dh[1], g.hs[1], g.vs[1], x, y) - 128;
-    const int cr = chroma_at(base + g.plane_off[2], 8 * g.bw[2], g.dw[2], g.dh[2], g.hs[2], g.vs[2], x, y) - 128;
-    r = clamp255(Y + ((91881 * cr + 32768) >> 16));
-    gg = clamp255(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
-    b = clamp255(Y + ((116130 * cb + 32768) >> 16));
+  if (g.ncomp == 1) return (unsigned)Y * 0x010101u;
+  const int cb = chroma_at(base + g.plane_off[1], 8 * g.bw[1], g.dw[1], g.dh[1], g.hs[1], g.vs[1], x, y) - 128;
+  const int cr = chroma_at(base + g.plane_off[2], 8 * g.bw[2], g.dw[2], g.dh[2], g.hs[2], g.vs[2], x, y) - 128;
+  const unsigned r = clamp255(Y + ((91881 * cr + 32768) >> 16));
+  const unsigned gg = clamp255(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
+  const unsigned b = clamp255(Y + ((116130 * cb + 32768) >> 16));
+  return r | (gg << 8) | (b << 16);
+}
+
+// grid (pixel groups of one image, image): four consecutive pixels of an image per thread (a group may straddle a row end), ONE
+// integer division per thread; when an image is a whole number of dwords (W * H % 4 == 0) the 12 bytes leave as three aligned dword
+// stores -- the first form of this kernel spent its time on a 64-bit division per pixel and on byte stores.
+__global__ __launch_bounds__(256) void jpeg_color_kernel(const unsigned char* __restrict__ planes, unsigned char* __restrict__ rgb, JpegGeom g) {
+  const unsigned npix = (unsigned)g.W * (unsigned)g.H;
+  const unsigned p0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (p0 >= npix) return;
+  const unsigned img = blockIdx.y;
+  const unsigned char* base = planes + (size_t)img * g.plane_bytes;
+  unsigned char* out = rgb + ((size_t)img * npix + p0) * 3;
+  int y = (int)(p0 / (unsigned)g.W), x = (int)(p0 - (unsigned)y * (unsigned)g.W);
+  unsigned px[4];
+  const int n = npix - p0 < 4u ? (int)(npix - p0) : 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    px[k] = k < n ? jpeg_pixel(base, g, x, y) : 0u;
+    if (++x == g.W) {
+      x = 0;
+      ++y;
+    }
   }
-  unsigned char* o = rgb + (size_t)t * 3;
-  o[0] = (unsigned char)r;
-  o[1] = (unsigned char)gg;
-  o[2] = (unsigned char)b;
+  if (n == 4 && (npix & 3u) == 0u) {
+    unsigned* o = reinterpret_cast<unsigned*>(out);
+    o[0] = px[0] | (px[1] << 24);
+    o[1] = (px[1] >> 8) | (px[2] << 16);
+    o[2] = (px[2] >> 16) | (px[3] << 8);
+  } else {
+    for (int k = 0; k < n; ++k) {
+      out[3 * k] = (unsigned char)px[k];
+      out[3 * k + 1] = (unsigned char)(px[k] >> 8);
+      out[3 * k + 2] = (unsigned char)(px[k] >> 16);
+    }
+  }
 }
 
 int make_jpeg_geom(const bdv_jpeg_info* info, JpegGeom& g, const char* who) {
@@ -591,15 +628,16 @@ extern "C" int bdv_jpeg_reconstruct_u8(const short* coefs, const unsigned short*
   JpegGeom g;
   if (int e = make_jpeg_geom(info, g, "bdv_jpeg_reconstruct_u8")) return e;
   BDV_REQUIRE(coefs && qts && workspace && rgb && B > 0, "bdv_jpeg_reconstruct_u8: null pointer / empty batch");
+  BDV_REQUIRE((((uintptr_t)rgb) & 3) == 0, "bdv_jpeg_reconstruct_u8: rgb must be 4-byte aligned");
   BDV_REQUIRE(bdv_aligned16(coefs) && bdv_aligned16(qts) && bdv_aligned16(workspace), "bdv_jpeg_reconstruct_u8: coefs, qts and workspace must be 16-byte aligned");
   BDV_REQUIRE(workspace_bytes >= (size_t)g.plane_bytes * B, "bdv_jpeg_reconstruct_u8: workspace %zu < required %zu bytes", workspace_bytes, (size_t)g.plane_bytes * B);
-  BDV_REQUIRE((long long)g.blocks_total * B < (1ll << 31) && (long long)g.W * g.H * B / 256 < (1ll << 31), "bdv_jpeg_reconstruct_u8: batch too large for one launch");
+  BDV_REQUIRE((long long)g.blocks_total * B < (1ll << 31) && B <= 65535 && (long long)g.W * g.H < (1ll << 31), "bdv_jpeg_reconstruct_u8: batch too large for one launch (at most 65535 images)");
   hipStream_t s = (hipStream_t)stream;
   const int nb = (int)(((long long)g.blocks_total * B + 255) / 256);
   hipLaunchKernelGGL(jpeg_idct_kernel, dim3(nb), dim3(256), 0, s, coefs, qts, (unsigned char*)workspace, g, B);
   BDV_LAUNCH_CHECK("bdv_jpeg_reconstruct_u8(idct)");
-  const long long npx = (long long)g.W * g.H * B;
-  hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, (const unsigned char*)workspace, rgb, g, B);
+  const unsigned groups = ((unsigned)g.W * (unsigned)g.H + 3u) / 4u;   // four pixels per thread
+  hipLaunchKernelGGL(jpeg_color_kernel, dim3((groups + 255u) / 256u, (unsigned)B), dim3(256), 0, s, (const unsigned char*)workspace, rgb, g);
   BDV_LAUNCH_CHECK("bdv_jpeg_reconstruct_u8(color)");
   return BDV_OK;
 }
