@@ -50,7 +50,7 @@ from .hooks import OutputHook, rgetattr  # noqa: F401
 from .optim import (CILTSMOptimizerConstructor, CILTSMOptimizerConstructorImprovised, FusedSGD, build_lr_scheduler,  # noqa: F401
                     build_optimizer)
 from .frontend import BackgroundCropFrontEnd, BackgroundMixFrontEnd, CropFrontEnd, MultiScaleCropResize, TrainClipFrontEnd, crop_offsets  # noqa: F401
-from .decode import JpegDecoder, RawFrameClipLoader, sample_frames  # noqa: F401
+from .decode import JpegDecoder, PrefetchLoader, RawFrameClipLoader, sample_frames  # noqa: F401
 from .augment import RandAugment  # noqa: F401
 from .cil_step import (TrainEngine, base_training_step, icarl_training_step, icarl_video_mix_training_step,  # noqa: F401
                        tubemix_draw)

@@ -252,3 +252,49 @@ class RawFrameClipLoader:
                 'clip_len': torch.ones(B, dtype=torch.int64, device=dev),
                 'num_clips': torch.full((B,), self.T, dtype=torch.int64, device=dev),
                 'frame_inds': torch.from_numpy(inds).to(dev)}
+
+
+class PrefetchLoader:
+    """Runs a ``clip_loader`` one batch ahead on a worker thread and its own HIP stream, so that reading, the Huffman stage, the
+    per-sample draws and the decode / augment kernels of batch i + 1 overlap the training step of batch i (the reference gets the same
+    from its DataLoader workers).  ``submit(video_infos, phase)`` queues a batch, ``get()`` returns the oldest queued batch after making
+    the caller's stream wait for it; or iterate: ``for batch in PrefetchLoader(loader).iterate(list_of_video_info_lists, phase)``.
+    The batch's tensors are handed to the consumer's stream with ``record_stream`` (a handful of tensors per step)."""
+
+    def __init__(self, loader, depth: int = 2):
+        self.loader, self.depth = loader, max(1, int(depth))
+        self.stream = torch.cuda.Stream()
+        self.pool = ThreadPoolExecutor(max_workers=1)
+        self.queue = []
+
+    def _work(self, video_infos, phase):
+        with torch.cuda.stream(self.stream):
+            batch = self.loader(video_infos, phase)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return batch, ev
+
+    def submit(self, video_infos, phase: str):
+        self.queue.append(self.pool.submit(self._work, video_infos, phase))
+
+    def get(self):
+        batch, ev = self.queue.pop(0).result()
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        for v in batch.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+        return batch
+
+    def iterate(self, batches_of_infos, phase: str):
+        it = iter(batches_of_infos)
+        for infos in it:
+            self.submit(infos, phase)
+            if len(self.queue) >= self.depth:
+                break
+        for infos in it:
+            out = self.get()
+            self.submit(infos, phase)
+            yield out
+        while self.queue:
+            yield self.get()

@@ -140,3 +140,24 @@ def test_train_pipeline(rawframes, dev):
     # (3) backgrounds drawn from the dataset's own frames when no bg_files are given (comix_loader.py:134-137)
     b = RawFrameClipLoader(dev, threads=2)(infos, 'train')
     assert tuple(b['imgs'].shape) == (4, 8, 3, 224, 224)
+
+
+def test_prefetch_loader_returns_the_loaders_batches(rawframes, dev):
+    """One batch ahead on a worker thread and a second stream: the same batches, in order (deterministic phases bit for bit; the train
+    phase under the same seeds, since the worker makes the same draws in the same order)."""
+    from bdvcil_amd.decode import PrefetchLoader, RawFrameClipLoader
+    infos, bgs = rawframes
+    loader = RawFrameClipLoader(dev, bg_files=bgs, threads=2)
+    lists = [infos[:2], infos[2:], infos[1:3], infos]
+    want = [loader(l, 'val') for l in lists]
+    got = list(PrefetchLoader(loader, depth=2).iterate(lists, 'val'))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert torch.equal(g['imgs'], w['imgs']) and torch.equal(g['label'], w['label']) and g['frame_dir'] == w['frame_dir']
+    np.random.seed(3); random.seed(3); torch.manual_seed(3)
+    want = [loader(l, 'train') for l in lists]
+    np.random.seed(3); random.seed(3); torch.manual_seed(3)
+    got = list(PrefetchLoader(loader, depth=3).iterate(lists, 'train'))
+    for g, w in zip(got, want):
+        assert torch.equal(g['randAug'], w['randAug']) and torch.equal(g['frame_inds'], w['frame_inds'])
+        assert torch.equal(g['imgs'], w['imgs'])

@@ -85,3 +85,41 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 print(f'Resize(-1, 256) of the batch (240 x 320 -> 256 x 341): {ms * 1e3:.0f} us, {(frames.numel() + r.numel()) / ms / 1e6:.0f} GB/s')
+
+# the whole train pipeline of the configs from files: SampleFrames -> read -> decode -> Resize(-1, 256) -> RandAugment -> MultiScaleCrop +
+# Resize(224) -> Normalize + background mix, 32 clips per batch (RawFrameClipLoader), frames in a temporary directory (page cache)
+import shutil
+import tempfile
+
+from bdvcil_amd.decode import RawFrameClipLoader
+
+root = tempfile.mkdtemp(prefix='bdv_frames_')
+try:
+    infos = []
+    for v in range(32):
+        d = os.path.join(root, f'v_{v}')
+        os.makedirs(d)
+        for i in range(1, 41):
+            with open(os.path.join(d, f'img_{i:05}.jpg'), 'wb') as f:
+                f.write(streams[(v * 7 + i) % 256])
+        infos.append({'frame_dir': d, 'total_frames': 40, 'label': v % 10})
+    bgs = []
+    for k in range(8):
+        p = os.path.join(root, f'bg_{k}.jpg')
+        with open(p, 'wb') as f:
+            f.write(streams[k])
+        bgs.append(p)
+    for threads in (4, 8, 16):
+        loader = RawFrameClipLoader(dev, bg_files=bgs, threads=threads)
+        for phase in ('train', 'val', 'test'):
+            loader(infos, phase)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                b = loader(infos, phase)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            print(f'RawFrameClipLoader {phase:5s} pipeline, {threads:2d} host threads: {dt * 1e3:6.1f} ms per batch of 32 clips = {32 / dt:5.0f} clips/s '
+                  f'-> imgs {tuple(b["imgs"].shape)}')
+finally:
+    shutil.rmtree(root, ignore_errors=True)
