@@ -65,6 +65,21 @@ class _Bucket:
                 off += p.numel()
 
 
+_COMM_STREAMS = {}
+
+
+def _comm_stream(device) -> 'torch.cuda.Stream':
+    """ONE communication stream per device for every reducer of the process.  HIP maps a process's streams onto GPU_MAX_HW_QUEUES
+    hardware queues and streams that share a queue run in order: a second reducer with a stream of its own (a second model in one
+    process, e.g. bench.py's alt_arith run) pushed the weight-gradient stream onto a shared queue and cost 12 ms per step
+    (profiles/r03_ab.txt item 9)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _COMM_STREAMS.get(idx)
+    if st is None:
+        st = _COMM_STREAMS[idx] = torch.cuda.Stream(device=device)
+    return st
+
+
 class GradAllReducer:
     def __init__(self, module: torch.nn.Module, bucket_cap_mb: float = 25.0, process_group=None, tail_cap_mb: float = 2.0):
         self.group = process_group
@@ -148,7 +163,7 @@ class GradAllReducer:
             from .functional import join_side_stream
             join_side_stream(b.flat.device)         # weight gradients are produced on the wgrad side stream
             if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(device=b.flat.device)
+                self._comm_stream = _comm_stream(b.flat.device)
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())
             self._comm_stream.wait_event(ready)

@@ -215,6 +215,28 @@ def cpu_baseline(depth, num_classes, head, loss, budget_s=25.0):
                        f'(torch {torch.__version__} CPU, fp32)')
 
 
+_JSON_FD = None
+
+
+def quiet_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner when the first
+    communicator comes up): from here on file descriptor 1 is the process's stderr, and ``emit`` writes the line to the real stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + '\n').encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def self_launch(n, argv):
     """``python bench.py --gpus N`` without torchrun: run ``torch.distributed.run`` with N ranks on 127.0.0.1 as a child
     process (this process never initialises the GPU), pass the child's output through and return its exit code."""
@@ -264,9 +286,8 @@ def selftest_cpu(args, world, rank):
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({'metric': 'launcher selftest', 'value': float(x[0]), 'n_gpus': world, 'steps': args.steps,
-                          'warmup': args.warmup, 'ms_per_step': float(t) * 1e3,
-                          'config': dist_record(reducer, world)}), flush=True)
+        emit({'metric': 'launcher selftest', 'value': float(x[0]), 'n_gpus': world, 'steps': args.steps,
+              'warmup': args.warmup, 'ms_per_step': float(t) * 1e3, 'config': dist_record(reducer, world)})
     dist.barrier()
     dist.destroy_process_group()
     return 0
@@ -310,6 +331,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks')
+    quiet_stdout()
     if args.selftest_cpu:
         return selftest_cpu(args, world, rank)
     if not torch.cuda.is_available():
@@ -591,7 +613,7 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline and not cil and not predict and not i3d:
             res['cpu_baseline'] = cpu_baseline(args.depth, args.classes, args.head, args.loss)
-        print(json.dumps(res), flush=True)
+        emit(res)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
