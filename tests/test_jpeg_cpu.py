@@ -145,3 +145,143 @@ def test_batch_host_stage_equals_per_image_calls():
     Image.fromarray(_picture(40, 64, 0, rng)).save(buf, 'JPEG')
     with pytest.raises((HipExtensionError, RuntimeError), match='image 5.*geometry'):
         run(streams[:5] + [buf.getvalue()] + streams[5:], 3)
+
+
+# ---- streams Pillow cannot write: per-component (non-interleaved) scans, 16-bit quantisation tables -----------------------------
+def _huff_code_table(counts, symbols):
+    """Annex C: symbol -> (code, length)."""
+    table, code, k = {}, 0, 0
+    for length in range(1, 17):
+        for _ in range(counts[length - 1]):
+            table[symbols[k]] = (code, length)
+            code += 1
+            k += 1
+        code <<= 1
+    return table
+
+
+class _BitWriter:
+    def __init__(self):
+        self.out, self.acc, self.n = bytearray(), 0, 0
+
+    def put(self, code, length):
+        self.acc = (self.acc << length) | (code & ((1 << length) - 1))
+        self.n += length
+        while self.n >= 8:
+            b = (self.acc >> (self.n - 8)) & 0xFF
+            self.out.append(b)
+            if b == 0xFF:
+                self.out.append(0)
+            self.n -= 8
+
+    def flush(self):
+        if self.n:
+            self.put((1 << (8 - self.n)) - 1, 8 - self.n)      # pad with ones
+        return bytes(self.out)
+
+
+def _encode_blocks(blocks, dc_tab, ac_tab):
+    """Baseline Huffman coding (F.1.2) of a sequence of natural-order coefficient blocks of ONE component."""
+    w, pred = _BitWriter(), 0
+    for blk in blocks:
+        zz = [int(blk[J.ZIGZAG[k]]) for k in range(64)]
+        diff = zz[0] - pred
+        pred = zz[0]
+        s = 0 if diff == 0 else int(abs(diff)).bit_length()
+        w.put(*dc_tab[s])
+        if s:
+            w.put(diff if diff > 0 else diff + (1 << s) - 1, s)
+        run = 0
+        last = max([k for k in range(1, 64) if zz[k] != 0], default=0)
+        for k in range(1, last + 1):
+            if zz[k] == 0:
+                run += 1
+                continue
+            while run > 15:
+                w.put(*ac_tab[0xF0])
+                run -= 16
+            s = int(abs(zz[k])).bit_length()
+            w.put(*ac_tab[(run << 4) | s])
+            w.put(zz[k] if zz[k] > 0 else zz[k] + (1 << s) - 1, s)
+            run = 0
+        if last < 63:
+            w.put(*ac_tab[0x00])
+    return w.flush()
+
+
+def _segments(data):
+    """(marker, payload) of every segment before the first SOS, plus the parsed tables."""
+    p, out = 2, []
+    while True:
+        m = data[p + 1]
+        L = (data[p + 2] << 8) | data[p + 3]
+        if m == 0xDA:
+            return out
+        out.append((m, data[p + 4:p + 2 + L]))
+        p += 2 + L
+
+
+def _non_interleaved(data, wide_tables=False):
+    """Re-codes a one-scan 4:2:0 / 4:4:4 stream from Pillow as three one-component scans over each component's own block grid
+    (A.2.3), optionally with the quantisation tables rewritten in their 16-bit form (Pq = 1)."""
+    info = J.parse(data)
+    coefs = J.entropy_decode(data, info)
+    geo = J.geometry(info)
+    out = bytearray(b'\xff\xd8')
+    tabs = {}
+    for m, payload in _segments(data):
+        if m == 0xC4:
+            q = 0
+            while q < len(payload):
+                tc, th = payload[q] >> 4, payload[q] & 15
+                counts = list(payload[q + 1:q + 17])
+                n = sum(counts)
+                tabs[(tc, th)] = _huff_code_table(counts, list(payload[q + 17:q + 17 + n]))
+                q += 17 + n
+        if m == 0xDB and wide_tables:
+            q, new = 0, bytearray()
+            while q < len(payload):
+                tq = payload[q] & 15
+                new.append(0x10 | tq)
+                for v in payload[q + 1:q + 65]:
+                    new += bytes([0, v])
+                q += 65
+            payload = bytes(new)
+        if 0xE0 <= m <= 0xEF:
+            continue
+        out += bytes([0xFF, m]) + (len(payload) + 2).to_bytes(2, 'big') + payload
+    sel = {c['id']: (0, 0) if i == 0 else (1, 1) for i, c in enumerate(info['comps'])}       # Pillow: tables 0 for luma, 1 for chroma
+    for ci, (c, g) in enumerate(zip(info['comps'], geo['comps'])):
+        nbx, nby = -(-g['dw'] // 8), -(-g['dh'] // 8)
+        blocks = [coefs[ci][by, bx] for by in range(nby) for bx in range(nbx)]
+        td, ta = sel[c['id']]
+        out += b'\xff\xda' + (8).to_bytes(2, 'big') + bytes([1, c['id'], (td << 4) | ta, 0, 63, 0])
+        out += _encode_blocks(blocks, tabs[(0, td)], tabs[(1, ta)])
+    return bytes(out + b'\xff\xd9'), info, coefs
+
+
+def test_per_component_scans_and_wide_tables():
+    """Streams no Pillow option produces, built by re-coding Pillow's coefficients: three one-component scans (each over its own
+    block grid, without the MCU padding) and 16-bit quantisation tables.  Pillow / libjpeg-turbo decodes them too: the oracle, the
+    host stage and Pillow must agree with each other and with the interleaved original."""
+    from PIL import Image
+    from bdvcil_amd.decode import jpeg_entropy_decode
+    rng = np.random.default_rng(17)
+    for (h, w, sub, wide) in ((33, 65, 2, False), (17, 23, 0, False), (40, 56, 2, True), (24, 40, 1, True)):
+        buf = io.BytesIO()
+        Image.fromarray(_picture(h, w, 0, rng)).save(buf, 'JPEG', quality=80, subsampling=sub)
+        orig = buf.getvalue()
+        data, info, coefs = _non_interleaved(orig, wide)
+        ref = np.asarray(Image.open(io.BytesIO(data)).convert('RGB'))
+        assert np.array_equal(ref, np.asarray(Image.open(io.BytesIO(orig)).convert('RGB')))      # the re-coding kept every coefficient
+        assert np.array_equal(J.decode(data), ref)
+        assert len(J.parse(data)['scans']) == 3
+        got_info, got = jpeg_entropy_decode(data)
+        geo = J.geometry(info)
+        off = 0
+        for ci, g in enumerate(geo['comps']):
+            nbx, nby = -(-g['dw'] // 8), -(-g['dh'] // 8)
+            want = np.zeros_like(coefs[ci])
+            want[:nby, :nbx] = coefs[ci][:nby, :nbx]              # blocks of the MCU padding are not coded in a one-component scan
+            assert np.array_equal(got[off:off + want.size].reshape(want.shape), want), ci
+            off += want.size

@@ -76,3 +76,19 @@ def test_batch_rules(dev):
         dec.decode([])
     with pytest.raises(ValueError, match='lengths'):
         dec.decode_clips([[a.getvalue()], [a.getvalue(), a.getvalue()]])
+
+
+def test_per_component_scans_on_the_gpu(dev):
+    """Non-interleaved scans and 16-bit quantisation tables (streams built by tests/test_jpeg_cpu.py's re-coder): the padding blocks
+    of the MCU grid are never coded there, stay zero, and must not reach the picture."""
+    from PIL import Image
+    from bdvcil_amd.decode import JpegDecoder
+    from test_jpeg_cpu import _non_interleaved
+    rng = np.random.default_rng(23)
+    dec = JpegDecoder(dev, threads=2)
+    for (h, w, sub, wide) in ((33, 65, 2, False), (17, 23, 0, True), (24, 40, 1, True)):
+        buf = io.BytesIO()
+        Image.fromarray(_picture(h, w, 1, rng)).save(buf, 'JPEG', quality=85, subsampling=sub)
+        data, _, _ = _non_interleaved(buf.getvalue(), wide)
+        want = np.asarray(Image.open(io.BytesIO(data)).convert('RGB'))
+        assert np.array_equal(dec.decode([data, buf.getvalue()]).cpu().numpy(), np.stack([want, want]))
