@@ -456,12 +456,49 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const unsigned char* __
   int y = (int)(p0 / (unsigned)g.W), x = (int)(p0 - (unsigned)y * (unsigned)g.W);
   unsigned px[4];
   const int n = npix - p0 < 4u ? (int)(npix - p0) : 4;
+  if (g.ncomp == 3 && g.hs[1] == 2 && g.vs[1] == 2 && g.dw[1] > 2 && x + 3 < g.W) {
+    // 4:2:0, the four pixels in one row: they need the chroma column sums (3 * this row + the nearer row) of at most five
+    // neighbouring columns, loaded ONCE for the group; with the column index clamped the edge forms of the filter
+    // ((4 cs + 8) >> 4, (4 cs + 7) >> 4) are the interior forms with cs[c - 1] = cs[c] resp. cs[c + 1] = cs[c]
+    const int dw = g.dw[1], dh = g.dh[1], i = y >> 1, c_lo = x >> 1;
+    int nb = (y & 1) ? i + 1 : i - 1;
+    nb = nb < 0 ? 0 : nb >= dh ? dh - 1 : nb;
+    int cs[2][5];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    px[k] = k < n ? jpeg_pixel(base, g, x, y) : 0u;
-    if (++x == g.W) {
-      x = 0;
-      ++y;
+    for (int pl = 0; pl < 2; ++pl) {
+      const unsigned char* cp = base + g.plane_off[1 + pl];
+      const int pitch = 8 * g.bw[1 + pl];
+      const unsigned char* r0 = cp + (size_t)i * pitch;
+      const unsigned char* r1 = cp + (size_t)nb * pitch;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        int c = c_lo - 1 + j;
+        c = c < 0 ? 0 : c >= dw ? dw - 1 : c;
+        cs[pl][j] = 3 * r0[c] + r1[c];
+      }
+    }
+    const unsigned char* yp = base + g.plane_off[0] + (size_t)y * 8 * g.bw[0] + x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int xi = x + k, j = (xi >> 1) - c_lo + 1;      // 1 .. 3
+      int cc[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        cc[pl] = ((xi & 1) ? (3 * cs[pl][j] + cs[pl][j + 1] + 7) >> 4 : (3 * cs[pl][j] + cs[pl][j - 1] + 8) >> 4) - 128;
+      const int Y = yp[k], cb = cc[0], cr = cc[1];
+      const unsigned r = clamp255(Y + ((91881 * cr + 32768) >> 16));
+      const unsigned gg = clamp255(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
+      const unsigned b = clamp255(Y + ((116130 * cb + 32768) >> 16));
+      px[k] = r | (gg << 8) | (b << 16);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      px[k] = k < n ? jpeg_pixel(base, g, x, y) : 0u;
+      if (++x == g.W) {
+        x = 0;
+        ++y;
+      }
     }
   }
   if (n == 4 && (npix & 3u) == 0u) {
