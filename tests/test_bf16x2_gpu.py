@@ -145,3 +145,21 @@ def test_short_training_run_follows_the_oracle(dev, bf16x2):
     assert hip_curve[-1] < hip_curve[0]
     for a, b in zip(hip_curve, ref_curve):
         assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (hip_curve, ref_curve)
+
+
+def test_i3d_eval_logits(dev, bf16x2):
+    """The arithmetic reaches the I3D blocks too (k x 1 temporal sites and per-frame sites run the same plane kernels): I3D-R50 eval
+    logits at 8 x 64 x 64, arg-max equal.  The I3D head is a plain linear layer on features of a random-init network evaluated with
+    fresh running statistics, so the logits are not O(1) (largest: 90.7): the bar is relative, 1e-4 of the largest logit (measured 1.4e-3 absolute = 1.6e-5 relative; probabilities: 1e-5)."""
+    from test_i3d_gpu import _pair
+    ref, mod = _pair(9, dev)
+    imgs = torch.randn(2, 2, 3, 8, 64, 64, generator=torch.Generator().manual_seed(3))
+    ref.eval(); mod.eval()
+    with torch.no_grad():
+        for mode in ('prob', 'score'):
+            ref.test_cfg['average_clips'] = mod.test_cfg['average_clips'] = mode
+            r = ref(imgs, return_loss=False)
+            o = mod(imgs.to(dev), return_loss=False).cpu()
+            e, scale = (o - r).abs().max().item(), max(1.0, r.abs().max().item())
+            assert e <= (1e-5 if mode == 'prob' else 1e-4 * scale), (mode, e, scale)
+            assert torch.equal(o.argmax(1), r.argmax(1))
